@@ -1,0 +1,176 @@
+"""CPU: the oracle (oracle/swiftnet_oracle.py) against golden vectors produced
+by running the reference itself (tests/golden/make_golden.py).  Tolerance 1e-5
+relative (same torch CPU kernels underneath; differences are summation order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swiftnet_oracle as O
+
+RTOL = 2e-5
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def close(a, b, rtol=RTOL, atol=None):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    scale = max(np.abs(b).max(), 1e-30)
+    atol = rtol * scale if atol is None else atol
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+STEP_CASES = [
+    ("step_supcon_pixel_focal_b2_64x128.npz", "supcon_pixelcontrast_focal", dict(b=2, h=64, w=128, seed=10, two=True), 123),
+    ("step_pixel_focal_b2_96x160.npz", "pixelcontrast_focal", dict(b=2, h=96, w=160, seed=11, two=False), 7),
+    ("step_ce_b2_64x128.npz", "crossentropy", dict(b=2, h=64, w=128, seed=12, two=False), 1),
+]
+
+
+@pytest.mark.parametrize("fname,criterion,shape,rng_seed", STEP_CASES)
+def test_train_step_matches_reference(golden_dir, fname, criterion, shape, rng_seed):
+    g = load(golden_dir, fname)
+    state = O.make_state(seed=1)
+    proj = O.make_proj(seed=2)
+    img, labels, ldw, weather, cw = O.synthetic_batch(shape["b"], shape["h"], shape["w"], seed=shape["seed"],
+                                                      two_crops=shape["two"], cell=16)
+    opt = O.Adam(state)
+    torch.manual_seed(rng_seed)
+    labels = labels.clone()
+    out, grads, gproj = O.train_step(state, proj, opt, img, labels, ldw, weather, cw, criterion, 2)
+    close(out["total"], g["total"])
+    for k in ("supcon", "pixel", "seg", "ce"):
+        if out[k] is not None:
+            close(out[k], g[k])
+    close(out["before"], g["before"])
+    close(out["fine_feat"], g["fine_feat"])
+    close(out["seg_logits"][:, :, ::4, ::4], g["seg_logits_sub"])
+    assert np.array_equal(out["seg_logits"].argmax(1).numpy().astype(np.uint8), g["seg_argmax"])
+    if criterion != "crossentropy":
+        # focal loss mutates the caller's labels in place (utils/loss.py:43)
+        assert np.array_equal(labels.numpy().astype(np.int16), g["labels_after"])
+    if "anchors" in out:
+        img_idx, cls, pix = out["anchors"]
+        assert np.array_equal(cls.numpy().astype(np.float32), g["anchor_y"])
+        ff = torch.from_numpy(g["fine_feat"])
+        b0 = shape["b"]
+        x = ff[:b0].permute(0, 2, 3, 1).reshape(b0, -1, 128)
+        close(x[img_idx.unsqueeze(1), pix], g["anchor_x"])
+    names = [str(s) for s in g["grad_names"]]
+    for k, n, s in zip(names, g["grad_norms"], g["grad_sums"]):
+        if n < 0:
+            assert grads.get(k) is None or float(grads[k].abs().max()) == 0.0, k
+            continue
+        gn = float(grads[k].norm())
+        assert abs(gn - n) <= 1e-4 * max(n, 1e-6) + 1e-7, (k, gn, n)
+    for key in g.files:
+        if key.startswith("grad::"):
+            close(grads[key[6:]], g[key], rtol=1e-4)
+        if key.startswith("post::"):
+            v = state[key[6:]]
+            if "num_batches" in key:
+                assert int(v) == int(g[key]), key
+            else:
+                close(v, g[key], rtol=1e-4)
+    for i, gp in enumerate(gproj):
+        if f"proj_grad_{i}" in g.files:
+            close(gp, g[f"proj_grad_{i}"], rtol=1e-4)
+    pn = {str(k): float(v) for k, v in zip(g["post_names"], g["post_norms"])}
+    for k, v in pn.items():
+        mine = float(state[k].double().norm())
+        assert abs(mine - v) <= 1e-5 * max(v, 1.0), (k, mine, v)
+
+
+def test_bn_update_multiplicity(golden_dir):
+    """block BNs are updated 6x per step (3 levels x checkpoint
+    recompute), stem / downsample / decoder / head BNs once per call."""
+    g = load(golden_dir, "step_ce_b2_64x128.npz")
+    assert int(g["post::feature_extractor.layer1.0.bn1.num_batches_tracked"]) == 6
+    assert int(g["post::feature_extractor.layer2.0.downsample.1.num_batches_tracked"]) == 3
+    assert int(g["post::feature_extractor.bn1_0.num_batches_tracked"]) == 1
+    assert int(g["post::feature_extractor.upsample_blends5.blend_conv.norm.num_batches_tracked"]) == 1
+    assert int(g["post::segmentation.norm.num_batches_tracked"]) == 1
+
+
+def test_eval_forward_odd_size(golden_dir):
+    g = load(golden_dir, "eval_fwd_b1_120x200.npz")
+    state = O.make_state(seed=1)
+    img = O.synthetic_batch(1, 120, 200, seed=13)[0]
+    with torch.no_grad():
+        seg, before, ff, _ = O.weathernet_forward(img, state, training=False)
+    close(before, g["before"])
+    close(ff, g["fine_feat"])
+    close(seg[:, :, ::4, ::4], g["seg_logits_sub"])
+    assert np.array_equal(seg.argmax(1).numpy().astype(np.uint8), g["seg_argmax"])
+
+
+def test_loss_units(golden_dir):
+    g = load(golden_dir, "loss_units.npz")
+    # pixel contrast
+    feats = torch.from_numpy(g["pix_feats"]).requires_grad_(True)
+    torch.manual_seed(99)
+    loss, sel = O.pixel_contrast_loss(feats, torch.from_numpy(g["pix_labels"]).long(),
+                                      torch.from_numpy(g["pix_logits"]), return_indices=True)
+    loss.backward()
+    close(loss.detach(), g["pix_loss"])
+    assert np.array_equal(sel[1].numpy().astype(np.float32), g["pix_anchor_y"])
+    close(feats.grad, g["pix_grad_feats"], rtol=1e-4)
+    # supcon / simclr
+    proj = [p.requires_grad_(True) for p in O.make_proj(seed=5)]
+    f = torch.from_numpy(g["sup_feats"]).requires_grad_(True)
+    l1 = O.supcon_loss(f, proj, torch.from_numpy(g["sup_weather"]))
+    l1.backward()
+    close(l1.detach(), g["sup_loss"])
+    close(f.grad, g["sup_grad_feats"], rtol=1e-4)
+    close(proj[0].grad, g["sup_grad_w1"], rtol=1e-4)
+    close(proj[3].grad, g["sup_grad_b2"], rtol=1e-4)
+    f2 = torch.from_numpy(g["sup_feats"]).requires_grad_(True)
+    l2 = O.supcon_loss(f2, [p.detach() for p in proj], None)
+    l2.backward()
+    close(l2.detach(), g["simclr_loss"])
+    close(f2.grad, g["simclr_grad_feats"], rtol=1e-4)
+    # focal variants
+    cw = torch.from_numpy(g["foc_cw"])
+    ldw = torch.from_numpy(g["foc_ldw"])
+    for variant in ("full", "plain_focal", "no_class_weights", "no_EDT"):
+        lg = torch.from_numpy(g["foc_logits"]).requires_grad_(True)
+        t = torch.from_numpy(g["foc_target"]).long()
+        lv = O.boundary_aware_focal_loss(lg, t, ldw, cw, variant=variant)
+        lv.backward()
+        close(lv.detach(), g[f"foc_loss_{variant}"])
+        close(lg.grad, g[f"foc_grad_{variant}"], rtol=1e-4)
+    lr_ = torch.from_numpy(g["foc_lr_logits"]).requires_grad_(True)
+    lv = O.boundary_aware_focal_loss(lr_, torch.from_numpy(g["foc_target"]).long(), ldw, cw)
+    lv.backward()
+    close(lv.detach(), g["foc_lr_loss"])
+    close(lr_.grad, g["foc_lr_grad"], rtol=1e-4)
+    lg = torch.from_numpy(g["foc_logits"]).requires_grad_(True)
+    lce = O.cross_entropy_loss(lg, torch.from_numpy(g["foc_target"]).long())
+    lce.backward()
+    close(lce.detach(), g["ce_loss"])
+    close(lg.grad, g["ce_grad"], rtol=1e-4)
+    close(O.weather_classifier(torch.from_numpy(g["sup_feats"]), torch.from_numpy(g["clf_w"]),
+                               torch.from_numpy(g["clf_b"])), g["clf_out"])
+
+
+def test_focal_no_valid_pixels_returns_zero():
+    lg = torch.zeros(1, 19, 4, 4, requires_grad=True)
+    t = torch.full((1, 4, 4), 255, dtype=torch.long)
+    out = O.boundary_aware_focal_loss(lg, t, torch.zeros(1, 4, 4), torch.ones(19))
+    assert float(out) == 0.0 and int(t.max()) == 0
+
+
+def test_sampling_edge_cases():
+    # no class with > max_views pixels -> None (utils/loss.py:287-288)
+    lab = torch.full((1, 16), 255, dtype=torch.long)
+    assert O.hard_anchor_sampling_indices(lab, torch.zeros(1, 16, dtype=torch.long)) is None
+    # all-hard class: easy count 0 -> takes n_view hard pixels
+    lab = torch.zeros((1, 16), dtype=torch.long)
+    pred = torch.ones((1, 16), dtype=torch.long)
+    torch.manual_seed(0)
+    img_idx, cls, pix = O.hard_anchor_sampling_indices(lab, pred)
+    assert pix.shape == (1, 2) and int(cls[0]) == 0
