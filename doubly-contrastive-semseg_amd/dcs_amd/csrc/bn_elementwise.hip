@@ -1,0 +1,370 @@
+// HBM-bound kernels around the convolutions: per-channel reductions, BatchNorm finalize /
+// apply / backward, fused residual + ReLU.  NHWC fp32, 16 B per lane, deterministic reductions
+// (fixed-order partial slabs, no float atomics).
+// Replaces nn.BatchNorm2d / nn.ReLU / residual add of network/backbone/resnet_pyramid.py:71-89
+// and network/utils.py:35-49 in the reference.
+#include "dcs_common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// partial[b][g][2][C]
+template <int MODE>
+__global__ __launch_bounds__(256)
+void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                           const float* __restrict__ masksrc, const float* __restrict__ bn,
+                           float* __restrict__ partial, long long rows, int C, int cstride, int groups, int relu) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][RL][C]
+  const int C4 = C >> 2;
+  const int RL = 256 / C4;
+  const int tid = threadIdx.x;
+  const int col4 = tid % C4, rl = tid / C4;
+  const int gi = blockIdx.x, b = blockIdx.y;
+  const long long rpg = (rows + groups - 1) / groups;
+  const long long rbeg = (long long)gi * rpg;
+  const long long rend = rbeg + rpg < rows ? rbeg + rpg : rows;
+  const float* xb = x + (long long)b * rows * cstride;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  if (rl < RL) {
+    float4 sc, sh, mu, is;
+    if (MODE == 1) {
+      sc = ld4(bn + col4 * 4); sh = ld4(bn + C + col4 * 4);
+      mu = ld4(bn + 2 * C + col4 * 4); is = ld4(bn + 3 * C + col4 * 4);
+    }
+    for (long long r = rbeg + rl; r < rend; r += RL) {
+      const long long off = r * cstride + col4 * 4;
+      float4 v = ld4(xb + off);
+      if (MODE == 0) {
+        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y);
+        s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
+      } else {
+        const float4 yy = ld4(y + off);
+        if (masksrc) {
+          const float4 ms = ld4(masksrc + off);
+          v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f;
+          v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
+        } else if (relu) {
+          v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
+          v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
+        }
+        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+        s1.x = fmaf(v.x, (yy.x - mu.x) * is.x, s1.x); s1.y = fmaf(v.y, (yy.y - mu.y) * is.y, s1.y);
+        s1.z = fmaf(v.z, (yy.z - mu.z) * is.z, s1.z); s1.w = fmaf(v.w, (yy.w - mu.w) * is.w, s1.w);
+      }
+    }
+    st4(&sm[(0 * RL + rl) * C + col4 * 4], s0);
+    st4(&sm[(1 * RL + rl) * C + col4 * 4], s1);
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * C; t += 256) {
+    const int which = t / C, c = t - which * C;
+    float s = 0.f;
+    for (int k = 0; k < RL; ++k) s += sm[(which * RL + k) * C + c];
+    partial[(((long long)b * groups + gi) * 2 + which) * C + c] = s;
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int groups, int C,
+                                    float scale) {
+  const int b = blockIdx.x;
+  for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) {
+    const int which = t / C, c = t - which * C;
+    double s = 0.0;
+    for (int gi = 0; gi < groups; ++gi) s += (double)partial[(((long long)b * groups + gi) * 2 + which) * C + c];
+    out[((long long)b * 2 + which) * C + c] = (float)(s * (double)scale);
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv,
+                                   float* __restrict__ bn, int C, double count, float eps, float momentum,
+                                   int repeats, int training) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, invstd;
+  if (training) {
+    const double m = (double)sums[c] / count;
+    double var = (double)sums[C + c] / count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean = (float)m;
+    invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (rm) {
+      const float vu = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+      float a = rm[c], b = rv[c];
+      for (int k = 0; k < repeats; ++k) {
+        a = (1.f - momentum) * a + momentum * mean;
+        b = (1.f - momentum) * b + momentum * vu;
+      }
+      rm[c] = a; rv[c] = b;
+    }
+  } else {
+    mean = rm[c];
+    invstd = 1.f / sqrtf(rv[c] + eps);
+  }
+  const float sc = gamma[c] * invstd;
+  bn[c] = sc;
+  bn[C + c] = fmaf(-mean, sc, beta[c]);
+  bn[2 * C + c] = mean;
+  bn[3 * C + c] = invstd;
+}
+
+__global__ void bn_ema_again_kernel(const float* __restrict__ bn, float* __restrict__ rm, float* __restrict__ rv,
+                                    int C, double count, float eps, float momentum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float mean = bn[2 * C + c];
+  const double is = (double)bn[3 * C + c];
+  double var = 1.0 / (is * is) - (double)eps;
+  if (var < 0.0) var = 0.0;
+  const float vu = (float)(var * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+  rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+  rv[c] = (1.f - momentum) * rv[c] + momentum * vu;
+}
+
+__global__ __launch_bounds__(256)
+void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bn, const float* __restrict__ r,
+                   const float* __restrict__ bn2, float* __restrict__ z, long long n4, int C, int relu) {
+  const int C4 = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const float4 v = ld4(y + i * 4);
+    const float4 sc = ld4(bn + c), sh = ld4(bn + C + c);
+    float4 o;
+    o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
+    if (r) {
+      float4 q = ld4(r + i * 4);
+      if (bn2) {
+        const float4 s2 = ld4(bn2 + c), h2 = ld4(bn2 + C + c);
+        q.x = fmaf(q.x, s2.x, h2.x); q.y = fmaf(q.y, s2.y, h2.y); q.z = fmaf(q.z, s2.z, h2.z); q.w = fmaf(q.w, s2.w, h2.w);
+      }
+      o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
+    }
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    st4(z + i * 4, o);
+  }
+}
+
+__global__ __launch_bounds__(256)
+void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ masksrc,
+                         const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
+                         float* __restrict__ dy, float* __restrict__ gm_out, float* __restrict__ dgamma,
+                         float* __restrict__ dbeta, long long rows, int C, int relu, int acc_dy, int acc_gm,
+                         int acc_param) {
+  const int C4 = C >> 2;
+  const long long n4 = rows * C4;
+  const float inv = (float)(1.0 / (double)rows);
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dbeta[c] = (acc_param ? dbeta[c] : 0.f) + sums[c];
+      dgamma[c] = (acc_param ? dgamma[c] : 0.f) + sums[C + c];
+    }
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    float4 v = ld4(g + i * 4);
+    const float4 yy = ld4(y + i * 4);
+    const float4 sc = ld4(bn + c), sh = ld4(bn + C + c), mu = ld4(bn + 2 * C + c), is = ld4(bn + 3 * C + c);
+    if (masksrc) {
+      const float4 ms = ld4(masksrc + i * 4);
+      v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f; v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
+    } else if (relu) {
+      v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
+      v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
+    }
+    if (gm_out) {
+      float4 o = v;
+      if (acc_gm) { const float4 p = ld4(gm_out + i * 4); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      st4(gm_out + i * 4, o);
+    }
+    if (dy) {
+      const float4 gw = ld4(gamma + c), s0 = ld4(sums + c), s1 = ld4(sums + C + c);
+      float4 o;
+      o.x = gw.x * is.x * (v.x - s0.x * inv - (yy.x - mu.x) * is.x * (s1.x * inv));
+      o.y = gw.y * is.y * (v.y - s0.y * inv - (yy.y - mu.y) * is.y * (s1.y * inv));
+      o.z = gw.z * is.z * (v.z - s0.z * inv - (yy.z - mu.z) * is.z * (s1.z * inv));
+      o.w = gw.w * is.w * (v.w - s0.w * inv - (yy.w - mu.w) * is.w * (s1.w * inv));
+      if (acc_dy) { const float4 p = ld4(dy + i * 4); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+      st4(dy + i * 4, o);
+    }
+  }
+}
+
+__global__ void scale_inplace_kernel(float* __restrict__ x, long long n, const float* __restrict__ a,
+                                     const float* __restrict__ b) {
+  const float s = a[0] * (b ? b[0] : 1.f);
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    float4 v = ld4(x + i * 4);
+    v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+    st4(x + i * 4, v);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) x[n4 * 4 + threadIdx.x] *= s;
+}
+
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long long n, float a) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    y[i] = fmaf(a, x[i], y[i]);
+}
+
+__global__ void add_rowvec_bcast_kernel(float* __restrict__ g, const float* __restrict__ v, long long HW, int C,
+                                        float scale, long long n4) {
+  const int C4 = C >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const long long n = i / (HW * C4);
+    const float4 a = ld4(v + n * C + c);
+    float4 o = ld4(g + i * 4);
+    o.x = fmaf(scale, a.x, o.x); o.y = fmaf(scale, a.y, o.y); o.z = fmaf(scale, a.z, o.z); o.w = fmaf(scale, a.w, o.w);
+    st4(g + i * 4, o);
+  }
+}
+
+__global__ void relu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ z, float* __restrict__ out,
+                                long long n) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = z[i] > 0.f ? g[i] : 0.f;
+}
+
+__global__ void sum_scalar_kernel(const float* __restrict__ x, float* __restrict__ out, int n, float scale) {
+  __shared__ double sm[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = (float)(sm[0] * (double)scale);
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, long long n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2s) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    const float gr = fmaf(wd, w, g[i]);
+    const float mi = b1 * m[i] + (1.f - b1) * gr;
+    const float vi = b2 * v[i] + (1.f - b2) * gr * gr;
+    m[i] = mi; v[i] = vi;
+    const float denom = sqrtf(vi) / bc2s + eps;
+    p[i] = w - (lr / bc1) * (mi / denom);
+  }
+}
+
+inline unsigned grid_for(long long n, int per = 256, unsigned cap = 8192) {
+  long long b = (n + per - 1) / per;
+  if (b < 1) b = 1;
+  return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int dcs_colsum_partial(const float* x, const float* y, const float* masksrc, const float* bn,
+                                  float* partial, int B, int64_t rows, int C, int cstride, int groups, int mode,
+                                  int relu, void* stream) {
+  DCS_CHECK_ARG(x && partial && B > 0 && rows > 0 && groups > 0 && C > 0 && (C & 3) == 0 && C <= 512);
+  DCS_CHECK_ARG((cstride & 3) == 0 && cstride >= C && dcs_aligned16(x));
+  DCS_CHECK_ARG(mode == 0 || (mode == 1 && y && bn && cstride == C));
+  const int C4 = C / 4, RL = 256 / C4;
+  const size_t sh = (size_t)2 * RL * C * sizeof(float);
+  dim3 grid((unsigned)groups, (unsigned)B);
+  if (mode == 0)
+    hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), sh, dcs_stream(stream), x, y, masksrc, bn, partial,
+                       (long long)rows, C, cstride, groups, relu);
+  else
+    hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), sh, dcs_stream(stream), x, y, masksrc, bn, partial,
+                       (long long)rows, C, cstride, groups, relu);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale, void* stream) {
+  DCS_CHECK_ARG(partial && out && B > 0 && groups > 0 && C > 0);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)B), dim3(256), 0, dcs_stream(stream), partial, out, groups, C, scale);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float* bn, int C, double count, float eps, float momentum,
+                               int repeats, int training, void* stream) {
+  DCS_CHECK_ARG(gamma && beta && bn && C > 0 && (training ? sums != nullptr : (running_mean && running_var)));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, dcs_stream(stream), sums, gamma, beta,
+                     running_mean, running_var, bn, C, count, eps, momentum, repeats, training);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_bn_ema_again(const float* bn, float* running_mean, float* running_var, int C, double count,
+                                float eps, float momentum, void* stream) {
+  DCS_CHECK_ARG(bn && running_mean && running_var && C > 0);
+  hipLaunchKernelGGL(bn_ema_again_kernel, dim3((C + 127) / 128), dim3(128), 0, dcs_stream(stream), bn, running_mean,
+                     running_var, C, count, eps, momentum);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_bn_act(const float* y, const float* bn, const float* r, const float* bn2, float* z, int64_t rows,
+                          int C, int relu, void* stream) {
+  DCS_CHECK_ARG(y && bn && z && rows > 0 && C > 0 && (C & 3) == 0 && dcs_aligned16(y) && dcs_aligned16(z));
+  const long long n4 = (long long)rows * (C / 4);
+  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), y, bn, r, bn2, z, n4, C, relu);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
+                                const float* gamma, const float* sums, float* dy, float* gm_out, float* dgamma,
+                                float* dbeta, int64_t rows, int C, int relu, int acc_dy, int acc_gm, int acc_param,
+                                void* stream) {
+  DCS_CHECK_ARG(g && y && bn && rows > 0 && C > 0 && (C & 3) == 0);
+  DCS_CHECK_ARG(!dy || (gamma && sums));
+  DCS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || sums));
+  const long long n4 = (long long)rows * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
+                     sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_scale_inplace(float* x, int64_t n, const float* a, const float* b, void* stream) {
+  DCS_CHECK_ARG(x && a && n > 0 && dcs_aligned16(x));
+  hipLaunchKernelGGL(scale_inplace_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, dcs_stream(stream), x, (long long)n, a, b);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_axpy(float* y, const float* x, int64_t n, float a, void* stream) {
+  DCS_CHECK_ARG(x && y && n > 0);
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), y, x, (long long)n, a);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW, int C, float scale, void* stream) {
+  DCS_CHECK_ARG(g && v && N > 0 && HW > 0 && C > 0 && (C & 3) == 0);
+  const long long n4 = (long long)N * HW * (C / 4);
+  hipLaunchKernelGGL(add_rowvec_bcast_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, v, (long long)HW, C,
+                     scale, n4);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_relu_bwd_rows(const float* g, const float* z, float* out, int64_t n, void* stream) {
+  DCS_CHECK_ARG(g && z && out && n > 0);
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), g, z, out, (long long)n);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_sum_scalar(const float* x, float* out, int n, float scale, void* stream) {
+  DCS_CHECK_ARG(x && out && n > 0);
+  hipLaunchKernelGGL(sum_scalar_kernel, dim3(1), dim3(256), 0, dcs_stream(stream), x, out, n, scale);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                             float beta2, float eps, float wd, int step, void* stream) {
+  DCS_CHECK_ARG(p && g && m && v && n > 0 && step > 0);
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), p, g, m, v, (long long)n, lr, beta1,
+                     beta2, eps, wd, bc1, bc2s);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" const char* dcs_version(void) { return "dcs_hip 0.1 (gfx950)"; }

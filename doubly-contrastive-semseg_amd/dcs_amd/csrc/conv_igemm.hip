@@ -1,0 +1,480 @@
+// Convolution as implicit GEMM on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD).
+//
+// One gather kernel serves nn.Conv2d forward AND its data gradient (see DcsConvGeom in
+// include/dcs_hip.h); a second kernel computes the weight gradient split over pixel ranges.
+// They replace the ATen/cuDNN calls behind network/backbone/resnet_pyramid.py:23-25,:110-112,:139
+// and network/utils.py:46-47 in the reference.
+//
+// Tiling (gather kernel): block = 256 threads = 4 waves, BM = 128 output pixels x BN output
+// channels, K consumed in chunks of 32 input channels of one filter tap.  Operands are staged
+// through registers into LDS rows of 36 floats (32 + 4 pad): lane (row r, half h) reads its four
+// k values kk+4h .. kk+4h+3 with one conflict-free ds_read_b128 and feeds them to four
+// MFMA 32x32x2 issues (any k permutation is legal as long as A and B agree).
+// Global loads of chunk i+1 are issued before the 64 MFMAs of chunk i and written to the other
+// LDS buffer afterwards: one barrier per chunk.
+#include "dcs_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDK = 36;   // LDS row stride in floats: 144 B = 9 x 16 B, odd in 16-B slots
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+
+template <int BN>
+__global__ __launch_bounds__(256, 2)
+void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
+                        const float* __restrict__ bias, float* __restrict__ dst,
+                        const DcsConvGeom g, const int accumulate, const int ntiles) {
+  constexpr int WN = BN >= 64 ? 2 : 1;
+  constexpr int WM = 4 / WN;
+  constexpr int TM = BM / (WM * 32);
+  constexpr int TN = BN / (WN * 32);
+  constexpr int BROWS = BN / 32;
+
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+  __shared__ long long rowoff[BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int lrow = tid >> 3, lcol4 = tid & 7;
+
+  const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % ntiles, mtile = bid / ntiles;
+  const int co0 = ntile * BN;
+  const long long m0 = (long long)mtile * BM;
+  const long long TYX = (long long)g.TY * g.TX;
+  const long long M = (long long)g.N * TYX;
+
+  if (tid < BM) {
+    const long long m = m0 + tid;
+    long long off = -1;
+    if (m < M) {
+      const int n = (int)(m / TYX);
+      const int rem = (int)(m - (long long)n * TYX);
+      const int ty = rem / g.TX, tx = rem - ty * g.TX;
+      off = (((long long)n * g.DH + (ty * g.dsy + g.dy0)) * g.DW + (tx * g.dsx + g.dx0)) * g.dst_cstride;
+    }
+    rowoff[tid] = off;
+  }
+
+  int r_n[4], r_y[4], r_x[4];
+  bool r_ok[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m0 + lrow + 32 * i;
+    r_ok[i] = m < M;
+    const long long mm = r_ok[i] ? m : 0;
+    const int n = (int)(mm / TYX);
+    const int rem = (int)(mm - (long long)n * TYX);
+    const int ty = rem / g.TX, tx = rem - ty * g.TX;
+    r_n[i] = n; r_y[i] = ty * g.sy; r_x[i] = tx * g.sx;
+  }
+
+  const int kch = g.stem ? 1 : (g.K + BK - 1) / BK;
+  const int nch = g.ntaps * kch;
+
+  float4 ra[4], rb[BROWS];
+
+  auto load_chunk = [&](int ch) {
+    const int t = ch / kch;
+    const int c0 = (ch - t * kch) * BK;
+    const int oy = g.offy[t], ox = g.offx[t], wo = g.wofs[t];
+    const int kc = c0 + lcol4 * 4;
+    if (!g.stem) {
+      const bool kvalid = kc < g.K;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = r_y[i] + oy, ix = r_x[i] + ox;
+        const bool ok = r_ok[i] && kvalid && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+        const long long off = (((long long)r_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
+        ra[i] = ok ? ld4(src + off) : zero4();
+      }
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        const int co = co0 + lrow + 32 * i;
+        const bool ok = kvalid && co < g.Cout;
+        rb[i] = ok ? ld4(wgt + (long long)co * g.wstride + wo + kc) : zero4();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int iy = r_y[i] + oy, ix = r_x[i] + ox + lcol4;
+        const bool ok = r_ok[i] && lcol4 < 7 && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+        const long long off = (((long long)r_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride;
+        ra[i] = ok ? ld4(src + off) : zero4();
+      }
+#pragma unroll
+      for (int i = 0; i < BROWS; ++i) {
+        const int co = co0 + lrow + 32 * i;
+        rb[i] = co < g.Cout ? ld4(wgt + (long long)co * g.wstride + wo + kc) : zero4();
+      }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDK + lcol4 * 4]) = ra[i];
+#pragma unroll
+    for (int i = 0; i < BROWS; ++i)
+      *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * i) * LDK + lcol4 * 4]) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    const bool more = ch + 1 < nch;
+    if (more) load_chunk(ch + 1);
+    const float* Ab = &As[buf][(wm * TM * 32 + l31) * LDK + 4 * h];
+    const float* Bb = &Bs[buf][(wn * TN * 32 + l31) * LDK + 4 * h];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 8) {
+      float av[TM][4], bv[TN][4];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const float4 v = ld4(Ab + a * 32 * LDK + kk);
+        av[a][0] = v.x; av[a][1] = v.y; av[a][2] = v.z; av[a][3] = v.w;
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const float4 v = ld4(Bb + b * 32 * LDK + kk);
+        bv[b][0] = v.x; bv[b][1] = v.y; bv[b][2] = v.z; bv[b][3] = v.w;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = co0 + wn * TN * 32 + b * 32 + l31;
+      if (col >= g.Cout) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long ro = rowoff[row];
+        if (ro < 0) continue;
+        float* p = dst + ro + col;
+        float v = acc[a][b][r] + bv;
+        if (accumulate) v += *p;
+        *p = v;
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient: dW[co][tap][ci] = sum_m dy[m][co] * src[gather(m,tap)][ci]
+// Block = one (tap, co tile, ci tile) and one pixel range (split); pixels are the GEMM K dimension,
+// staged 32 at a time as [pixel][channel] rows, read column-wise by conflict-free ds_read_b32.
+template <int BT>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                       const DcsConvGeom g, const int dy_cstride, const int split0, const long long mps,
+                       const int ciT) {
+  constexpr int T = BT / 64;          // 32x32 tiles per wave per dim
+  constexpr int C4 = BT / 4;          // float4 per staged row
+  constexpr int RP = 256 / C4;        // rows per load pass
+  constexpr int NP = 32 / RP;         // passes per chunk
+  __shared__ __attribute__((aligned(16))) float Ds[2][32 * BT];
+  __shared__ __attribute__((aligned(16))) float Xs[2][32 * BT];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lcol4 = tid % C4, lrow = tid / C4;
+
+  const int bx = blockIdx.x;
+  const int t = bx % g.ntaps;
+  const int rest = bx / g.ntaps;
+  const int ciTile = rest % ciT, coTile = rest / ciT;
+  const int co0 = coTile * BT, ci0 = ciTile * BT;
+  const int split = blockIdx.y;
+
+  const long long TYX = (long long)g.TY * g.TX;
+  const long long M = (long long)g.N * TYX;
+  const long long mbeg = (long long)split * mps;
+  const long long mend = mbeg + mps < M ? mbeg + mps : M;
+  const int Keff = g.stem ? 32 : g.K;
+  const int oy = g.offy[t], ox = g.offx[t], wo = g.wofs[t];
+
+  // per-row-slot pixel coordinates, advanced incrementally (no division in the loop)
+  int p_n[NP], p_ty[NP], p_tx[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    long long m = mbeg + lrow + RP * i;
+    if (m >= M) m = M - 1;
+    const int n = (int)(m / TYX);
+    const int rem = (int)(m - (long long)n * TYX);
+    p_n[i] = n; p_ty[i] = rem / g.TX; p_tx[i] = rem - p_ty[i] * g.TX;
+  }
+
+  float4 rd[NP], rx[NP];
+  const int kc = ci0 + lcol4 * 4;
+  const int cc = co0 + lcol4 * 4;
+
+  auto load_chunk = [&](long long mc) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const long long m = mc + lrow + RP * i;
+      const bool mok = m < mend;
+      rd[i] = (mok && cc < g.Cout) ? ld4(dy + m * dy_cstride + cc) : zero4();
+      const int iy = p_ty[i] * g.sy + oy;
+      int ix = p_tx[i] * g.sx + ox;
+      bool ok = mok && (unsigned)iy < (unsigned)g.SH;
+      long long off;
+      if (!g.stem) {
+        ok = ok && kc < g.K && (unsigned)ix < (unsigned)g.SW;
+        off = (((long long)p_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
+      } else {
+        ix += lcol4;
+        ok = ok && lcol4 < 7 && (unsigned)ix < (unsigned)g.SW;
+        off = (((long long)p_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride;
+      }
+      rx[i] = ok ? ld4(src + off) : zero4();
+      // advance this slot by 32 pixels
+      p_tx[i] += 32;
+      while (p_tx[i] >= g.TX) { p_tx[i] -= g.TX; p_ty[i] += 1; }
+      while (p_ty[i] >= g.TY) { p_ty[i] -= g.TY; p_n[i] += 1; }
+    }
+  };
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      *reinterpret_cast<float4*>(&Ds[buf][(lrow + RP * i) * BT + lcol4 * 4]) = rd[i];
+      *reinterpret_cast<float4*>(&Xs[buf][(lrow + RP * i) * BT + lcol4 * 4]) = rx[i];
+    }
+  };
+
+  f32x16 acc[T][T];
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const long long nch = mend > mbeg ? (mend - mbeg + 31) / 32 : 0;
+  if (nch > 0) {
+    load_chunk(mbeg);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (long long ch = 0; ch < nch; ++ch) {
+    const int buf = (int)(ch & 1);
+    const bool more = ch + 1 < nch;
+    if (more) load_chunk(mbeg + (ch + 1) * 32);
+    const float* Db = &Ds[buf][wm * (BT / 2) + l31];
+    const float* Xb = &Xs[buf][wn * (BT / 2) + l31];
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 8) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int row = kk + 4 * h + j;
+        float av[T], bv[T];
+#pragma unroll
+        for (int a = 0; a < T; ++a) av[a] = Db[row * BT + a * 32];
+#pragma unroll
+        for (int b = 0; b < T; ++b) bv[b] = Xb[row * BT + b * 32];
+#pragma unroll
+        for (int a = 0; a < T; ++a)
+#pragma unroll
+          for (int b = 0; b < T; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
+      }
+    }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = slab + (long long)(split0 + split) * g.Cout * g.wstride;
+#pragma unroll
+  for (int a = 0; a < T; ++a)
+#pragma unroll
+    for (int b = 0; b < T; ++b) {
+      const int ci = ci0 + wn * (BT / 2) + b * 32 + l31;
+      if (ci >= Keff) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * (BT / 2) + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < g.Cout) out[(long long)co * g.wstride + wo + ci] = acc[a][b][r];
+      }
+    }
+}
+
+__global__ void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n,
+                                   int nsplit, int accumulate) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = accumulate ? dw[i] : 0.f;
+  for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * n + i];
+  dw[i] = s;
+}
+
+__global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int Cout, int RS,
+                                         int Cin) {
+  // o[ci][rs][co] = w[co][rs][ci]; thread per output element, co fastest
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n = (long long)Cout * RS * Cin;
+  if (i >= n) return;
+  const int co = (int)(i % Cout);
+  const long long q = i / Cout;
+  const int rs = (int)(q % RS);
+  const int ci = (int)(q / RS);
+  o[i] = w[((long long)co * RS + rs) * Cin + ci];
+}
+
+__global__ void pack_stem_weight_kernel(const float* __restrict__ in, float* __restrict__ out, int Cout, int dir) {
+  // dir 0: in [Cout][7][7][3] -> out [Cout][7][8][4] zero padded; dir 1: the inverse (drops pads)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dir == 0) {
+    if (i >= Cout * 7 * 32) return;
+    const int c = i & 3, s = (i >> 2) & 7, r = (i >> 5) % 7, co = i / 224;
+    out[i] = (c < 3 && s < 7) ? in[((co * 7 + r) * 7 + s) * 3 + c] : 0.f;
+  } else {
+    if (i >= Cout * 147) return;
+    const int c = i % 3, s = (i / 3) % 7, r = (i / 21) % 7, co = i / 147;
+    out[i] = in[((co * 7 + r) * 8 + s) * 4 + c];
+  }
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+  __shared__ float tile[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int r = by + j, c = bx + threadIdx.x;
+    if (r < R && c < C) tile[j][threadIdx.x] = in[(long long)r * C + c];
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int c = bx + j, r = by + threadIdx.x;
+    if (r < R && c < C) out[(long long)c * R + r] = tile[threadIdx.x][j];
+  }
+}
+
+int check_geom(const DcsConvGeom* g) {
+  DCS_CHECK_ARG(g != nullptr);
+  DCS_CHECK_ARG(g->N > 0 && g->SH > 0 && g->SW > 0 && g->DH > 0 && g->DW > 0 && g->TY > 0 && g->TX > 0);
+  DCS_CHECK_ARG(g->ntaps > 0 && g->ntaps <= DCS_MAX_TAPS && g->Cout > 0 && g->K > 0);
+  DCS_CHECK_ARG((g->wstride & 3) == 0 && (g->src_cstride & 3) == 0);
+  if (g->stem) {
+    DCS_CHECK_ARG(g->K == 4 && g->src_cstride == 4);
+  } else {
+    DCS_CHECK_ARG((g->K & 3) == 0);
+  }
+  for (int t = 0; t < g->ntaps; ++t) DCS_CHECK_ARG((g->wofs[t] & 3) == 0 && g->wofs[t] >= 0);
+  // destination sub-grid must stay inside the destination tensor
+  DCS_CHECK_ARG((g->TY - 1) * g->dsy + g->dy0 < g->DH && (g->TX - 1) * g->dsx + g->dx0 < g->DW);
+  DCS_CHECK_ARG(g->dy0 >= 0 && g->dx0 >= 0 && g->dsy > 0 && g->dsx > 0 && g->sy > 0 && g->sx > 0);
+  return DCS_OK;
+}
+
+}  // namespace
+
+extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
+                               const DcsConvGeom* geom, int accumulate, void* stream) {
+  int rc = check_geom(geom);
+  if (rc != DCS_OK) return rc;
+  DCS_CHECK_ARG(src && wgt && dst && dcs_aligned16(src) && dcs_aligned16(wgt));
+  DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout);
+  const long long M = (long long)geom->N * geom->TY * geom->TX;
+  const long long mtiles = (M + BM - 1) / BM;
+  const int bn = geom->Cout > 64 ? 128 : (geom->Cout > 32 ? 64 : 32);
+  const int ntiles = (geom->Cout + bn - 1) / bn;
+  const long long blocks = mtiles * ntiles;
+  DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
+  hipStream_t s = dcs_stream(stream);
+  if (bn == 128)
+    hipLaunchKernelGGL(conv_gather_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, *geom,
+                       accumulate, ntiles);
+  else if (bn == 64)
+    hipLaunchKernelGGL(conv_gather_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, *geom,
+                       accumulate, ntiles);
+  else
+    hipLaunchKernelGGL(conv_gather_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, *geom,
+                       accumulate, ntiles);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom,
+                              int dy_cstride, int split0, int nsplit, void* stream) {
+  int rc = check_geom(geom);
+  if (rc != DCS_OK) return rc;
+  DCS_CHECK_ARG(src && dy && slab && dcs_aligned16(src) && dcs_aligned16(dy));
+  DCS_CHECK_ARG((dy_cstride & 3) == 0 && dy_cstride >= geom->Cout && nsplit > 0 && split0 >= 0);
+  // the dy pixel index equals the GEMM row index: destination sub-grid must be the dense tensor
+  DCS_CHECK_ARG(geom->dsy == 1 && geom->dsx == 1 && geom->dy0 == 0 && geom->dx0 == 0 &&
+                geom->TY == geom->DH && geom->TX == geom->DW);
+  const long long M = (long long)geom->N * geom->TY * geom->TX;
+  long long mps = (M + nsplit - 1) / nsplit;
+  mps = (mps + 31) / 32 * 32;
+  const int keff = geom->stem ? 32 : geom->K;
+  const int bt = (geom->Cout > 64 && keff > 64) ? 128 : 64;
+  const int coT = (geom->Cout + bt - 1) / bt, ciT = (keff + bt - 1) / bt;
+  hipStream_t s = dcs_stream(stream);
+  dim3 grid((unsigned)(geom->ntaps * coT * ciT), (unsigned)nsplit);
+  if (bt == 128)
+    hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
+  else
+    hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, void* stream) {
+  DCS_CHECK_ARG(slab && dw && n > 0 && nsplit > 0);
+  hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dcs_stream(stream), slab, dw,
+                     (long long)n, nsplit, accumulate);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_pack_dgrad_weight(const float* w_krsc, float* w_crsk, int Cout, int R, int S, int Cin,
+                                     void* stream) {
+  DCS_CHECK_ARG(w_krsc && w_crsk && Cout > 0 && R > 0 && S > 0 && Cin > 0);
+  const long long n = (long long)Cout * R * S * Cin;
+  hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dcs_stream(stream),
+                     w_krsc, w_crsk, Cout, R * S, Cin);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_pack_stem_weight(const float* in, float* out, int Cout, int dir, void* stream) {
+  DCS_CHECK_ARG(in && out && Cout > 0 && (dir == 0 || dir == 1));
+  const int n = dir == 0 ? Cout * 224 : Cout * 147;
+  hipLaunchKernelGGL(pack_stem_weight_kernel, dim3((n + 255) / 256), dim3(256), 0, dcs_stream(stream), in, out, Cout, dir);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_transpose(const float* in, float* out, int R, int C, void* stream) {
+  DCS_CHECK_ARG(in && out && R > 0 && C > 0);
+  hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(32, 8), 0, dcs_stream(stream), in, out, R, C);
+  DCS_LAUNCH_RET();
+}

@@ -1,0 +1,364 @@
+// Segmentation losses, hard-anchor sampling and the row-wise part of the contrastive losses.
+// Replaces utils/loss.py:39-80 (BoundaryAwareFocalLoss), nn.CrossEntropyLoss, utils/loss.py:264-337
+// (_hard_anchor_sampling: counting / index selection; the random permutation stays on the host CPU
+// generator exactly like the reference) and utils/loss.py:175-204,:361-386 (row reductions of the
+// similarity matrix) in the reference.
+#include "dcs_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// seg loss: one thread per pixel, C logit planes (NCHW -> coalesced across lanes)
+template <int MAXC>
+__global__ __launch_bounds__(256)
+void seg_loss_kernel(const float* __restrict__ logits, int64_t* __restrict__ target, const float* __restrict__ ldw,
+                     const float* __restrict__ cw, float* __restrict__ grad, float* __restrict__ partial, int N, int C,
+                     long long HW, int mode, float gamma, int ignore) {
+  __shared__ double sl[256];
+  __shared__ double sc[256];
+  const long long total = (long long)N * HW;
+  double lsum = 0.0, lcnt = 0.0;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW, p = i - n * HW;
+    const float* lp = logits + n * C * HW + p;
+    float* gp = grad + n * C * HW + p;
+    long long t = target[i];
+    float coef;
+    bool counted;
+    if (mode == 4) {                       // cross entropy, ignore_index
+      counted = t != ignore;
+      coef = counted ? 1.f : 0.f;
+      if (!counted || t < 0 || t >= C) t = 0;
+    } else {
+      if (t == ignore) { t = 0; target[i] = 0; }      // utils/loss.py:43 (in place)
+      if (t < 0 || t >= C) t = 0;
+      const float a = ldw[i];
+      counted = a > 0.f;                              // N = (ldw > 0).sum(), loss.py:45
+      coef = 1.f;                                     // filled below (needs pt)
+    }
+    float v[MAXC];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      v[c] = c < C ? lp[(long long)c * HW] : -INFINITY;
+      mx = fmaxf(mx, v[c]);
+    }
+    float se = 0.f, xt = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      v[c] = c < C ? expf(v[c] - mx) : 0.f;
+      se += v[c];
+      if (c == (int)t) xt = c < C ? lp[(long long)c * HW] : 0.f;
+    }
+    const float logpt = xt - mx - logf(se);
+    if (mode != 4) {
+      const float pt = expf(logpt);
+      const float mod = expf(gamma * (1.f - pt));
+      const float w = cw ? cw[t] : 1.f;
+      const float a = ldw[i];
+      coef = mode == 0 ? w * a * mod : (mode == 1 ? mod : (mode == 2 ? a * mod : w * mod));
+    }
+    lsum += (double)(-coef * logpt);
+    lcnt += counted ? 1.0 : 0.0;
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c)
+      if (c < C) gp[(long long)c * HW] = -coef * ((c == (int)t ? 1.f : 0.f) - v[c] * inv);
+  }
+  sl[threadIdx.x] = lsum; sc[threadIdx.x] = lcnt;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = (float)sl[0]; partial[2 * blockIdx.x + 1] = (float)sc[0]; }
+}
+
+__global__ void seg_loss_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int blocks) {
+  __shared__ double sl[256];
+  __shared__ double sc[256];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < blocks; i += 256) { a += (double)partial[2 * i]; b += (double)partial[2 * i + 1]; }
+  sl[threadIdx.x] = a; sc[threadIdx.x] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sl[threadIdx.x] += sl[threadIdx.x + o]; sc[threadIdx.x] += sc[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const double cnt = sc[0];
+    out[0] = cnt > 0.0 ? (float)(sl[0] / cnt) : 0.f;
+    out[1] = (float)cnt;
+    out[2] = cnt > 0.0 ? (float)(1.0 / cnt) : 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// hard-anchor sampling, device half
+__global__ __launch_bounds__(256)
+void anchor_keys_kernel(const float* __restrict__ logits, int cs, int C, const int64_t* __restrict__ labels, int h,
+                        int w, int H, int W, int ignore, uint8_t* __restrict__ key, int32_t* __restrict__ hist,
+                        int chunk, int nchunks) {
+  __shared__ int lh[64];
+  const int n = blockIdx.y, ck = blockIdx.x;
+  const int HW = h * w;
+  if (threadIdx.x < 64) lh[threadIdx.x] = 0;
+  __syncthreads();
+  const float sy = (float)H / (float)h, sx = (float)W / (float)w;
+  for (int q = threadIdx.x; q < chunk; q += 256) {
+    const int p = ck * chunk + q;
+    if (p >= HW) break;
+    const int y = p / w, x = p - y * w;
+    const float* lp = logits + ((long long)n * HW + p) * cs;
+    float best = lp[0];
+    int bi = 0;
+    for (int c = 1; c < C; ++c) { const float v = lp[c]; if (v > best) { best = v; bi = c; } }
+    // F.interpolate(mode='nearest'): src = min(floor(dst * in/out), in - 1)   (utils/loss.py:400-403)
+    int yy = (int)floorf((float)y * sy); if (yy > H - 1) yy = H - 1;
+    int xx = (int)floorf((float)x * sx); if (xx > W - 1) xx = W - 1;
+    const long long lab = labels[((long long)n * H + yy) * W + xx];
+    int k = 255;
+    if (lab != ignore && lab >= 0 && lab < C) {
+      k = (int)lab * 2 + (bi == (int)lab ? 1 : 0);
+      atomicAdd(&lh[k], 1);
+    }
+    key[(long long)n * HW + p] = (uint8_t)k;
+  }
+  __syncthreads();
+  if (threadIdx.x < 2 * C) hist[((long long)n * nchunks + ck) * 2 * C + threadIdx.x] = lh[threadIdx.x];
+}
+
+__global__ __launch_bounds__(256)
+void anchor_select_kernel(const uint8_t* __restrict__ key, const int32_t* __restrict__ hist,
+                          const int32_t* __restrict__ req, int32_t* __restrict__ out, int HW, int C, int chunk,
+                          int nchunks) {
+  __shared__ int s_chunk, s_local;
+  __shared__ int cnt[256];
+  const int q = blockIdx.x;
+  const int n = req[3 * q], k = req[3 * q + 1], rank = req[3 * q + 2];
+  if (threadIdx.x == 0) {
+    int cum = 0, ck = 0;
+    s_chunk = -1;
+    for (; ck < nchunks; ++ck) {
+      const int c = hist[((long long)n * nchunks + ck) * 2 * C + k];
+      if (rank < cum + c) { s_chunk = ck; s_local = rank - cum; break; }
+      cum += c;
+    }
+  }
+  __syncthreads();
+  if (s_chunk < 0) { if (threadIdx.x == 0) out[q] = -1; return; }
+  const int per = chunk / 256;
+  const int base = s_chunk * chunk + threadIdx.x * per;
+  int c = 0;
+  for (int j = 0; j < per; ++j) { const int p = base + j; if (p < HW && key[(long long)n * HW + p] == k) ++c; }
+  cnt[threadIdx.x] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int cum = 0;
+    for (int t = 0; t < 256; ++t) { const int v = cnt[t]; cnt[t] = cum; cum += v; }
+  }
+  __syncthreads();
+  int seen = cnt[threadIdx.x];
+  if (s_local >= seen && s_local < seen + c) {
+    for (int j = 0; j < per; ++j) {
+      const int p = base + j;
+      if (p < HW && key[(long long)n * HW + p] == k) { if (seen == s_local) { out[q] = p; break; } ++seen; }
+    }
+  }
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ feat, const int32_t* __restrict__ rowidx,
+                                   float* __restrict__ X, int A, int C) {
+  const int C4 = C >> 2;
+  const long long total = (long long)A * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(i / C4), c = (int)(i % C4) * 4;
+    *reinterpret_cast<float4*>(X + (long long)a * C + c) =
+        *reinterpret_cast<const float4*>(feat + (long long)rowidx[a] * C + c);
+  }
+}
+
+__global__ void scatter_add_rows_kernel(const float* __restrict__ gX, const int32_t* __restrict__ rowidx,
+                                        float* __restrict__ gfeat, int A, int C) {
+  // rows are unique (a pixel is sampled at most once), so a plain read-modify-write is race free
+  const int C4 = C >> 2;
+  const long long total = (long long)A * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(i / C4), c = (int)(i % C4) * 4;
+    float4* d = reinterpret_cast<float4*>(gfeat + (long long)rowidx[a] * C + c);
+    const float4 v = *reinterpret_cast<const float4*>(gX + (long long)a * C + c);
+    float4 o = *d;
+    o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+    *d = o;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// contrastive rows.  One 256-thread block per anchor row i.
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = dcs_wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = dcs_wave_max(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+__global__ __launch_bounds__(256)
+void contrast_rows_kernel(const float* __restrict__ S, const float* __restrict__ labels, float* __restrict__ loss_row,
+                          float* __restrict__ G, int A, int ld, int mode, float inv_temp, float inv_rows) {
+  __shared__ float sm[4];
+  const int i = blockIdx.x;
+  const float* s = S + (long long)i * ld;
+  float* gr = G + (long long)i * ld;
+  const float yi = labels[i];
+  // pass 1: row max of S/T (utils/loss.py:363, :179)
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < A; j += 256) mx = fmaxf(mx, s[j] * inv_temp);
+  mx = block_max(mx, sm);
+  // pass 2: ||S_i - max||_2, F.normalize eps 1e-12 (:366, :194)
+  float n2 = 0.f;
+  for (int j = threadIdx.x; j < A; j += 256) { const float u = s[j] * inv_temp - mx; n2 = fmaf(u, u, n2); }
+  n2 = block_sum(n2, sm);
+  const float nraw = sqrtf(n2);
+  const float nrm = fmaxf(nraw, 1e-12f);
+  const float rn = 1.f / nrm;
+  // pass 3: denominators / positive counts
+  float den = 0.f, cnt = 0.f;
+  for (int j = threadIdx.x; j < A; j += 256) {
+    const float L = (s[j] * inv_temp - mx) * rn;
+    const bool same = labels[j] == yi;
+    if (mode == 0) { if (!same) den += expf(L); }          // neg_logits (:376-377)
+    else { if (j != i) den += expf(L); }                   // exp_logits * logits_mask (:196)
+    if (same && j != i) cnt += 1.f;
+  }
+  den = block_sum(den, sm);
+  cnt = block_sum(cnt, sm);
+  // pass 4: sum over positives of log_prob, and q = sum_pos 1/(E+neg) (pixel mode)
+  float lp = 0.f, qv = 0.f;
+  for (int j = threadIdx.x; j < A; j += 256) {
+    if (j == i || labels[j] != yi) continue;
+    const float L = (s[j] * inv_temp - mx) * rn;
+    if (mode == 0) { const float d = expf(L) + den; lp += L - logf(d); qv += 1.f / d; }
+    else lp += L - logf(den);
+  }
+  lp = block_sum(lp, sm);
+  qv = block_sum(qv, sm);
+  if (threadIdx.x == 0) loss_row[i] = -lp / cnt;              // temperature/base_temperature = 1
+  // pass 5: dL_j, then through F.normalize: du = (dL - L * <dL, L>) / nrm
+  float dot = 0.f;
+  for (int j = threadIdx.x; j < A; j += 256) {
+    const float L = (s[j] * inv_temp - mx) * rn;
+    const float E = expf(L);
+    const bool same = labels[j] == yi;
+    float dL;
+    if (mode == 0) dL = same ? (j != i ? -(den / (E + den)) / cnt : 0.f) : E * qv / cnt;
+    else dL = (j != i ? E / den : 0.f) - ((same && j != i) ? 1.f / cnt : 0.f);
+    dot = fmaf(dL, L, dot);
+  }
+  dot = block_sum(dot, sm);
+  const bool clamp = nraw <= 1e-12f;
+  for (int j = threadIdx.x; j < ld; j += 256) {
+    float o = 0.f;
+    if (j < A) {
+      const float L = (s[j] * inv_temp - mx) * rn;
+      const float E = expf(L);
+      const bool same = labels[j] == yi;
+      float dL;
+      if (mode == 0) dL = same ? (j != i ? -(den / (E + den)) / cnt : 0.f) : E * qv / cnt;
+      else dL = (j != i ? E / den : 0.f) - ((same && j != i) ? 1.f / cnt : 0.f);
+      o = (clamp ? dL : (dL - L * dot)) * rn * inv_rows * inv_temp;
+    }
+    gr[j] = o;
+  }
+}
+
+__global__ void symmetrize_kernel(const float* __restrict__ G, float* __restrict__ Gs, int A, int ld) {
+  const long long total = (long long)A * ld;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int r = (int)(i / ld), c = (int)(i % ld);
+    Gs[i] = c < A ? G[i] + G[(long long)c * ld + r] : 0.f;
+  }
+}
+
+inline unsigned grid_for(long long n, unsigned cap = 8192) {
+  long long b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int dcs_seg_loss(const float* logits, int64_t* target, const float* ldw, const float* cw, float* grad,
+                            float* partial, int N, int C, int H, int W, int mode, float gamma, int ignore, int blocks,
+                            void* stream) {
+  DCS_CHECK_ARG(logits && target && grad && partial && N > 0 && C > 0 && C <= 32 && H > 0 && W > 0 && blocks > 0);
+  DCS_CHECK_ARG(mode >= 0 && mode <= 4 && (mode == 4 || mode == 1 || ldw));
+  DCS_CHECK_ARG(mode == 4 || ldw);
+  const long long HW = (long long)H * W;
+  if (C <= 20)
+    hipLaunchKernelGGL(seg_loss_kernel<20>, dim3((unsigned)blocks), dim3(256), 0, dcs_stream(stream), logits, target, ldw, cw,
+                       grad, partial, N, C, HW, mode, gamma, ignore);
+  else
+    hipLaunchKernelGGL(seg_loss_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, dcs_stream(stream), logits, target, ldw, cw,
+                       grad, partial, N, C, HW, mode, gamma, ignore);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_seg_loss_final(const float* partial, float* out, int blocks, void* stream) {
+  DCS_CHECK_ARG(partial && out && blocks > 0);
+  hipLaunchKernelGGL(seg_loss_final_kernel, dim3(1), dim3(256), 0, dcs_stream(stream), partial, out, blocks);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_anchor_keys(const float* logits, int cs, int C, const int64_t* labels, int N, int h, int w, int H,
+                               int W, int ignore, uint8_t* key, int32_t* hist, int chunk, void* stream) {
+  DCS_CHECK_ARG(logits && labels && key && hist && N > 0 && h > 0 && w > 0 && H > 0 && W > 0);
+  DCS_CHECK_ARG(C > 0 && C <= 32 && cs >= C && chunk > 0 && (chunk & 255) == 0);
+  const int nchunks = (h * w + chunk - 1) / chunk;
+  hipLaunchKernelGGL(anchor_keys_kernel, dim3((unsigned)nchunks, (unsigned)N), dim3(256), 0, dcs_stream(stream), logits, cs, C,
+                     labels, h, w, H, W, ignore, key, hist, chunk, nchunks);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_anchor_select(const uint8_t* key, const int32_t* hist, const int32_t* req, int32_t* out, int Q, int N,
+                                 int HW, int C, int chunk, void* stream) {
+  DCS_CHECK_ARG(key && hist && req && out && Q > 0 && N > 0 && HW > 0 && C > 0 && C <= 32 && chunk > 0 && (chunk & 255) == 0);
+  const int nchunks = (HW + chunk - 1) / chunk;
+  hipLaunchKernelGGL(anchor_select_kernel, dim3((unsigned)Q), dim3(256), 0, dcs_stream(stream), key, hist, req, out, HW, C,
+                     chunk, nchunks);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_gather_rows(const float* feat, const int32_t* rowidx, float* X, int A, int C, void* stream) {
+  DCS_CHECK_ARG(feat && rowidx && X && A > 0 && C > 0 && (C & 3) == 0);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for((long long)A * C / 4)), dim3(256), 0, dcs_stream(stream), feat, rowidx, X, A, C);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_scatter_add_rows(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, void* stream) {
+  DCS_CHECK_ARG(gX && rowidx && gfeat && A > 0 && C > 0 && (C & 3) == 0);
+  hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((long long)A * C / 4)), dim3(256), 0, dcs_stream(stream), gX, rowidx,
+                     gfeat, A, C);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_contrast_rows(const float* S, const float* labels, float* loss_row, float* G, int A, int ld, int mode,
+                                 float inv_temp, void* stream) {
+  DCS_CHECK_ARG(S && labels && loss_row && G && A > 0 && ld >= A && (mode == 0 || mode == 1));
+  hipLaunchKernelGGL(contrast_rows_kernel, dim3((unsigned)A), dim3(256), 0, dcs_stream(stream), S, labels, loss_row, G, A, ld,
+                     mode, inv_temp, 1.f / (float)A);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_symmetrize(const float* G, float* Gs, int A, int ld, void* stream) {
+  DCS_CHECK_ARG(G && Gs && A > 0 && ld >= A);
+  hipLaunchKernelGGL(symmetrize_kernel, dim3(grid_for((long long)A * ld)), dim3(256), 0, dcs_stream(stream), G, Gs, A, ld);
+  DCS_LAUNCH_RET();
+}

@@ -1,0 +1,363 @@
+// Image pyramid, stem max-pool and bilinear resizes (forward + adjoint), NHWC fp32.
+// All HBM-bound; backward passes are written as gathers (no float atomics -> deterministic).
+// Replaces F.interpolate / nn.MaxPool2d calls of network/backbone/resnet_pyramid.py:296-325 and
+// network/utils.py:8,:92-102 in the reference.
+#include "dcs_common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float4 f4axpy(float a, float4 x, float4 y) {
+  return make_float4(fmaf(a, x.x, y.x), fmaf(a, x.y, y.y), fmaf(a, x.z, y.z), fmaf(a, x.w, y.w));
+}
+__device__ __forceinline__ float4 f4scale(float a, float4 x) { return make_float4(a * x.x, a * x.y, a * x.z, a * x.w); }
+__device__ __forceinline__ float4 f4add(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+// ---- level 0: (x - mean) / std, NCHW -> NHWC4 -----------------------------------------------------
+__global__ void normalize_kernel(const float* __restrict__ img, float* __restrict__ out, int N, long long HW,
+                                 const float* __restrict__ mean3, const float* __restrict__ std3) {
+  const long long total = (long long)N * HW;
+  const float m0 = mean3[0], m1 = mean3[1], m2 = mean3[2], s0 = std3[0], s1 = std3[1], s2 = std3[2];
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long n = i / HW, p = i - n * HW;
+    const float* b = img + n * 3 * HW + p;
+    st4(out + i * 4, make_float4((b[0] - m0) / s0, (b[HW] - m1) / s1, (b[2 * HW] - m2) / s2, 0.f));
+  }
+}
+
+// ---- levels 1,2: bicubic (A=-0.75) at exact scale 1/f, f in {2,4}: fractional offset is always 0.5,
+// taps f*d + f/2 - 2 .. +1 with weights (-3/32, 19/32, 19/32, -3/32), indices clamped (resnet_pyramid.py:313)
+__global__ void bicubic_down_kernel(const float* __restrict__ x0, float* __restrict__ out, int N, int H, int W,
+                                    int OH, int OW, int f) {
+  const long long total = (long long)N * OH * OW;
+  const float wt[4] = {-0.09375f, 0.59375f, 0.59375f, -0.09375f};
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const long long q = i / OW;
+    const int oy = (int)(q % OH), n = (int)(q / OH);
+    const int by = f * oy + f / 2 - 2, bx = f * ox + f / 2 - 2;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const int iy = min(max(by + a, 0), H - 1);
+      float4 row = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const int ix = min(max(bx + b, 0), W - 1);
+        row = f4axpy(wt[b], ld4(x0 + (((long long)n * H + iy) * W + ix) * 4), row);
+      }
+      acc = f4axpy(wt[a], row, acc);
+    }
+    acc.w = 0.f;
+    st4(out + i * 4, acc);
+  }
+}
+
+// ---- stem: maxpool 3x3/2 pad 1 over relu(y*scale+shift), argmax kept as 0..8 -------------------------
+__global__ __launch_bounds__(256)
+void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ bn, float* __restrict__ out,
+                            uint8_t* __restrict__ idx, int N, int H, int W, int OH, int OW, int C) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * OH * OW * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int ox = (int)(q % OW); q /= OW;
+    const int oy = (int)(q % OH);
+    const int n = (int)(q / OH);
+    const float4 sc = ld4(bn + c), sh = ld4(bn + C + c);
+    float4 best = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    int b0 = 0, b1 = 0, b2 = 0, b3 = 0;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        if ((unsigned)ix >= (unsigned)W) continue;
+        const float4 v = ld4(y + (((long long)n * H + iy) * W + ix) * C + c);
+        const float z0 = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f), z1 = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+        const float z2 = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f), z3 = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        const int k = ky * 3 + kx;
+        if (z0 > best.x) { best.x = z0; b0 = k; }
+        if (z1 > best.y) { best.y = z1; b1 = k; }
+        if (z2 > best.z) { best.z = z2; b2 = k; }
+        if (z3 > best.w) { best.w = z3; b3 = k; }
+      }
+    }
+    st4(out + i * 4, best);
+    *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4((unsigned char)b0, (unsigned char)b1, (unsigned char)b2, (unsigned char)b3);
+  }
+}
+
+__global__ __launch_bounds__(256)
+void maxpool_bwd_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, float* __restrict__ gz, int N,
+                        int H, int W, int OH, int OW, int C) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * H * W * C4;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int ix = (int)(q % W); q /= W;
+    const int iy = (int)(q % H);
+    const int n = (int)(q / H);
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int ty = iy + 1 - ky;
+      if (ty < 0 || (ty & 1)) continue;
+      const int oy = ty >> 1;
+      if (oy >= OH) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx) {
+        const int tx = ix + 1 - kx;
+        if (tx < 0 || (tx & 1)) continue;
+        const int ox = tx >> 1;
+        if (ox >= OW) continue;
+        const long long o = (((long long)n * OH + oy) * OW + ox) * C + c;
+        const uchar4 id = *reinterpret_cast<const uchar4*>(idx + o);
+        const float4 gv = ld4(g + o);
+        const int k = ky * 3 + kx;
+        if (id.x == k) acc.x += gv.x;
+        if (id.y == k) acc.y += gv.y;
+        if (id.z == k) acc.z += gv.z;
+        if (id.w == k) acc.w += gv.w;
+      }
+    }
+    st4(gz + i * 4, acc);
+  }
+}
+
+// ---- bilinear, align_corners=False, explicit output size (torch area_pixel_compute_source_index) -----
+struct Lin { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lin lin_src(int o, float scale, int in) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  Lin l;
+  l.i0 = (int)s;
+  if (l.i0 > in - 1) l.i0 = in - 1;
+  l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+  l.w1 = s - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+// total weight with which input index i enters output o
+__device__ __forceinline__ float lin_w(int o, float scale, int in, int i) {
+  const Lin l = lin_src(o, scale, in);
+  float w = 0.f;
+  if (l.i0 == i) w += l.w0;
+  if (l.i1 == i) w += l.w1;
+  return w;
+}
+__device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, int& hi) {
+  // outputs o whose source coordinate lies in (i-1, i+1), widened by one on each side
+  const float inv = 1.f / scale;
+  lo = (int)floorf(((float)i - 1.f + 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.f + 0.5f) * inv - 0.5f) + 1;
+  if (lo < 0) lo = 0;
+  if (hi > out - 1) hi = out - 1;
+}
+
+__global__ __launch_bounds__(256)
+void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ s0, const float* __restrict__ s1,
+                         const float* __restrict__ s2, float* __restrict__ t, int N, int IH, int IW, int OH, int OW,
+                         int C) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * OH * OW * C4;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int ox = (int)(q % OW); q /= OW;
+    const int oy = (int)(q % OH);
+    const int n = (int)(q / OH);
+    const Lin ly = lin_src(oy, sy, IH), lx = lin_src(ox, sx, IW);
+    const float* b = x + (long long)n * IH * IW * C + c;
+    const float4 v00 = ld4(b + ((long long)ly.i0 * IW + lx.i0) * C), v01 = ld4(b + ((long long)ly.i0 * IW + lx.i1) * C);
+    const float4 v10 = ld4(b + ((long long)ly.i1 * IW + lx.i0) * C), v11 = ld4(b + ((long long)ly.i1 * IW + lx.i1) * C);
+    const float4 top = f4axpy(lx.w1, v01, f4scale(lx.w0, v00));
+    const float4 bot = f4axpy(lx.w1, v11, f4scale(lx.w0, v10));
+    float4 r = f4axpy(ly.w1, bot, f4scale(ly.w0, top));
+    if (s0) {
+      float4 sk = ld4(s0 + i * 4);          // python sum(): ((0 + s0) + s1) + s2, then x + skip
+      if (s1) sk = f4add(sk, ld4(s1 + i * 4));
+      if (s2) sk = f4add(sk, ld4(s2 + i * 4));
+      r = f4add(r, sk);
+    }
+    st4(t + i * 4, r);
+  }
+}
+
+__global__ __launch_bounds__(256)
+void upsample_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int N, int IH, int IW, int OH, int OW,
+                         int C, int accumulate) {
+  const int C4 = C >> 2;
+  const long long total = (long long)N * IH * IW * C4;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int ix = (int)(q % IW); q /= IW;
+    const int iy = (int)(q % IH);
+    const int n = (int)(q / IH);
+    int ylo, yhi, xlo, xhi;
+    out_range(iy, sy, OH, ylo, yhi);
+    out_range(ix, sx, OW, xlo, xhi);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = lin_w(oy, sy, IH, iy);
+      if (wy == 0.f) continue;
+      float4 row = make_float4(0, 0, 0, 0);
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = lin_w(ox, sx, IW, ix);
+        if (wx == 0.f) continue;
+        row = f4axpy(wx, ld4(g + (((long long)n * OH + oy) * OW + ox) * C + c), row);
+      }
+      acc = f4axpy(wy, row, acc);
+    }
+    if (accumulate) acc = f4add(acc, ld4(gx + i * 4));
+    st4(gx + i * 4, acc);
+  }
+}
+
+__global__ __launch_bounds__(256)
+void upsample_to_nchw_kernel(const float* __restrict__ x, float* __restrict__ out, int N, int IH, int IW, int cs, int C,
+                             int OH, int OW) {
+  const long long total = (long long)N * OH * OW;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ox = (int)(i % OW);
+    const long long q = i / OW;
+    const int oy = (int)(q % OH), n = (int)(q / OH);
+    const Lin ly = lin_src(oy, sy, IH), lx = lin_src(ox, sx, IW);
+    const float* b = x + (long long)n * IH * IW * cs;
+    const float* p00 = b + ((long long)ly.i0 * IW + lx.i0) * cs;
+    const float* p01 = b + ((long long)ly.i0 * IW + lx.i1) * cs;
+    const float* p10 = b + ((long long)ly.i1 * IW + lx.i0) * cs;
+    const float* p11 = b + ((long long)ly.i1 * IW + lx.i1) * cs;
+    float* o = out + (long long)n * C * OH * OW + (long long)oy * OW + ox;
+    for (int c = 0; c < C; ++c) {
+      const float top = fmaf(lx.w1, p01[c], lx.w0 * p00[c]);
+      const float bot = fmaf(lx.w1, p11[c], lx.w0 * p10[c]);
+      o[(long long)c * OH * OW] = fmaf(ly.w1, bot, ly.w0 * top);
+    }
+  }
+}
+
+// thread per (n, c, iy, ix), ix fastest: reads of g stay within a few adjacent rows of one plane
+__global__ __launch_bounds__(256)
+void upsample_to_nchw_bwd_kernel(const float* __restrict__ g, const float* __restrict__ gscale, float* __restrict__ gx,
+                                 int N, int IH, int IW, int cs, int C, int OH, int OW) {
+  const long long total = (long long)N * cs * IH * IW;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  const float gs = gscale ? gscale[0] : 1.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % IW);
+    long long q = i / IW;
+    const int iy = (int)(q % IH); q /= IH;
+    const int c = (int)(q % cs);
+    const int n = (int)(q / cs);
+    float acc = 0.f;
+    if (c < C) {
+      int ylo, yhi, xlo, xhi;
+      out_range(iy, sy, OH, ylo, yhi);
+      out_range(ix, sx, OW, xlo, xhi);
+      const float* gp = g + ((long long)n * C + c) * OH * OW;
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = lin_w(oy, sy, IH, iy);
+        if (wy == 0.f) continue;
+        float row = 0.f;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = lin_w(ox, sx, IW, ix);
+          if (wx != 0.f) row = fmaf(wx, gp[(long long)oy * OW + ox], row);
+        }
+        acc = fmaf(wy, row, acc);
+      }
+      acc *= gs;
+    }
+    gx[(((long long)n * IH + iy) * IW + ix) * cs + c] = acc;
+  }
+}
+
+inline unsigned grid_for(long long n, unsigned cap = 16384) {
+  long long b = (n + 255) / 256;
+  if (b < 1) b = 1;
+  return (unsigned)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+extern "C" int dcs_normalize_pyramid(const float* img, float* out0, float* out1, float* out2, int N, int H, int W,
+                                     const float* mean3, const float* std3, void* stream) {
+  DCS_CHECK_ARG(img && out0 && mean3 && std3 && N > 0 && H > 0 && W > 0);
+  hipStream_t s = dcs_stream(stream);
+  hipLaunchKernelGGL(normalize_kernel, dim3(grid_for((long long)N * H * W)), dim3(256), 0, s, img, out0, N,
+                     (long long)H * W, mean3, std3);
+  if (out1) {
+    DCS_CHECK_ARG(H / 2 > 0 && W / 2 > 0);
+    hipLaunchKernelGGL(bicubic_down_kernel, dim3(grid_for((long long)N * (H / 2) * (W / 2))), dim3(256), 0, s, out0, out1,
+                       N, H, W, H / 2, W / 2, 2);
+  }
+  if (out2) {
+    DCS_CHECK_ARG(H / 4 > 0 && W / 4 > 0);
+    hipLaunchKernelGGL(bicubic_down_kernel, dim3(grid_for((long long)N * (H / 4) * (W / 4))), dim3(256), 0, s, out0, out2,
+                       N, H, W, H / 4, W / 4, 4);
+  }
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_bn_relu_maxpool(const float* y, const float* bn, float* out, uint8_t* idx, int N, int H, int W, int C,
+                                   void* stream) {
+  DCS_CHECK_ARG(y && bn && out && idx && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long total = (long long)N * OH * OW * (C / 4);
+  hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), y, bn, out, idx, N, H,
+                     W, OH, OW, C);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_maxpool_bwd(const float* g, const uint8_t* idx, float* gz, int N, int H, int W, int C, void* stream) {
+  DCS_CHECK_ARG(g && idx && gz && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long total = (long long)N * H * W * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), g, idx, gz, N, H, W, OH,
+                     OW, C);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_upsample_add(const float* x, const float* s0, const float* s1, const float* s2, float* t, int N,
+                                int IH, int IW, int OH, int OW, int C, void* stream) {
+  DCS_CHECK_ARG(x && t && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && (C & 3) == 0);
+  DCS_CHECK_ARG(s0 || (!s1 && !s2));
+  const long long total = (long long)N * OH * OW * (C / 4);
+  hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), x, s0, s1, s2, t, N, IH,
+                     IW, OH, OW, C);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_upsample_bwd(const float* g, float* gx, int N, int IH, int IW, int OH, int OW, int C, int accumulate,
+                                void* stream) {
+  DCS_CHECK_ARG(g && gx && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && (C & 3) == 0);
+  const long long total = (long long)N * IH * IW * (C / 4);
+  hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), g, gx, N, IH, IW, OH, OW,
+                     C, accumulate);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_upsample_to_nchw(const float* x, float* out, int N, int IH, int IW, int cs, int C, int OH, int OW,
+                                    void* stream) {
+  DCS_CHECK_ARG(x && out && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && cs >= C);
+  hipLaunchKernelGGL(upsample_to_nchw_kernel, dim3(grid_for((long long)N * OH * OW)), dim3(256), 0, dcs_stream(stream), x,
+                     out, N, IH, IW, cs, C, OH, OW);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, float* gx, int N, int IH, int IW, int cs,
+                                        int C, int OH, int OW, void* stream) {
+  DCS_CHECK_ARG(g && gx && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && cs >= C);
+  hipLaunchKernelGGL(upsample_to_nchw_bwd_kernel, dim3(grid_for((long long)N * cs * IH * IW)), dim3(256), 0,
+                     dcs_stream(stream), g, gscale, gx, N, IH, IW, cs, C, OH, OW);
+  DCS_LAUNCH_RET();
+}

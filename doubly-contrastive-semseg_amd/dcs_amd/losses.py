@@ -1,0 +1,356 @@
+"""Drop-in loss modules with the reference's names and call signatures
+(utils/loss.py:27-80, :84-205, :208-247, :250-415), backed by HIP kernels.
+
+Each loss is one ``torch.autograd.Function``: forward launches the fused
+kernels (which already produce the gradient), backward only rescales it by
+the incoming scalar.  Host code that the reference also runs on the host
+(class filtering, ``torch.randperm`` on the CPU generator) stays on the host
+with identical RNG consumption.
+"""
+from __future__ import annotations
+
+from abc import ABC
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# --------------------------------------------------------------------------- #
+# layout helpers
+# --------------------------------------------------------------------------- #
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """[N,C,H,W]-shaped tensor -> contiguous [N,H,W,C] (free for channels_last inputs)."""
+    ops.require_device(x, "loss input")
+    v = x.permute(0, 2, 3, 1).contiguous()
+    return v if v.is_floating_point() else v.float()
+
+
+def _scalar(g: torch.Tensor) -> torch.Tensor:
+    return g.detach().reshape(1).contiguous()
+
+
+def global_avg_pool(x: torch.Tensor) -> torch.Tensor:
+    """nn.AdaptiveAvgPool2d((1,1)) + flatten on an [N,C,H,W]-shaped tensor -> [N,C]."""
+    v = nhwc(x.detach())
+    N, H, W, Cc = v.shape
+    return ops.colsum(v.reshape(N * H * W, Cc), B=N, scale=1.0 / (H * W))[:, 0, :].contiguous()
+
+
+# --------------------------------------------------------------------------- #
+# segmentation losses
+# --------------------------------------------------------------------------- #
+class _SegLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, ldw, cw, mode, gamma, ignore):
+        lg = logits.detach()
+        if not lg.is_contiguous():
+            lg = lg.contiguous()
+        out, grad = ops.seg_loss(lg, target, ldw, cw, mode, gamma, ignore)
+        ctx.grad, ctx.out = grad, out
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        if grad is None:
+            raise RuntimeError("seg loss backward called twice")
+        ctx.grad = None
+        ops.scale_inplace(grad, _scalar(g), ctx.out[2:3])
+        return grad, None, None, None, None, None, None
+
+
+class _UpsampleNCHWFn(torch.autograd.Function):
+    """upsample = F.interpolate(bilinear, align_corners=False) (utils/loss.py:5) on logits."""
+
+    @staticmethod
+    def forward(ctx, x, size):
+        v = nhwc(x.detach())
+        ctx.in_hw = v.shape[1:3]
+        ctx.cs = v.shape[3]
+        return ops.upsample_to_nchw(v, v.shape[3], size[0], size[1])
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = ops.upsample_to_nchw_bwd(g.contiguous(), ctx.in_hw[0], ctx.in_hw[1], ctx.cs)
+        return gx.permute(0, 3, 1, 2), None
+
+
+def _prep_target(target):
+    ops.require_device(target, "target")
+    if target.dtype != torch.int64:
+        raise RuntimeError("target must be an int64 tensor")
+    if not target.is_contiguous():
+        raise RuntimeError("target must be contiguous (it is rewritten in place like the reference)")
+    return target
+
+
+class BoundaryAwareFocalLoss(nn.Module):
+    """utils/loss.py:27-80.  ``target`` is rewritten in place (255 -> 0) like the reference."""
+
+    def __init__(self, gamma=0, num_classes=19, ignore_id=19, print_each=20, weight=None, device=None, opts=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self.ignore_id = ignore_id
+        self.print_each = print_each
+        self.step_counter = 0
+        self.gamma = gamma
+        self.weight = weight
+        self.device = device
+        self.opts = opts
+        self._cw = None
+
+    def _class_weight(self, dev):
+        if self.weight is None:
+            return None
+        if self._cw is None or self._cw.device != dev or self._cw.dtype != self.weight.dtype:
+            self._cw = self.weight.to(dev).contiguous()
+        return self._cw
+
+    def _mode(self):
+        o = self.opts
+        if getattr(o, "criterion", None) == "plain_focal":
+            return "plain_focal"
+        if getattr(o, "no_class_weights", False):
+            return "no_class_weights"
+        if getattr(o, "no_EDT", False):
+            return "no_EDT"
+        return "full"
+
+    def forward(self, input, target, batch, **kwargs):
+        if input.shape[-2:] != target.shape[-2:]:
+            input = _UpsampleNCHWFn.apply(input, tuple(target.shape[-2:]))
+        ldw = batch["label_distance_weight"].to(input.device, input.dtype).contiguous()
+        loss = _SegLossFn.apply(input, _prep_target(target), ldw, self._class_weight(input.device), self._mode(),
+                                float(self.gamma), int(self.ignore_id))
+        self.step_counter += 1
+        return loss
+
+
+class FocalLoss2(BoundaryAwareFocalLoss):
+    """utils/loss.py:208-247: the un-weighted variant (-exp(gamma(1-pt)) logpt / N)."""
+
+    def __init__(self, gamma=0, num_classes=19, ignore_id=19, print_each=20, weight=None, device=None):
+        super().__init__(gamma, num_classes, ignore_id, print_each, weight, device, opts=None)
+
+    def _mode(self):
+        return "plain_focal"
+
+
+class SemsegCrossEntropy(nn.Module):
+    """nn.CrossEntropyLoss(ignore_index) on the HIP kernel (utils/loss.py:6-24, init_trainer.py:223)."""
+
+    def __init__(self, num_classes=19, ignore_id=255, print_each=20):
+        super().__init__()
+        self.num_classes, self.ignore_id, self.step_counter, self.print_each = num_classes, ignore_id, 0, print_each
+
+    def forward(self, logits, labels, **kwargs):
+        if logits.shape[-2:] != labels.shape[-2:]:
+            logits = _UpsampleNCHWFn.apply(logits, tuple(labels.shape[-2:]))
+        self.step_counter += 1
+        return _SegLossFn.apply(logits, _prep_target(labels), None, None, "ce", 0.0, int(self.ignore_id))
+
+
+# --------------------------------------------------------------------------- #
+# image-level contrastive loss
+# --------------------------------------------------------------------------- #
+_ident_bn = {}
+
+
+def _identity_bn(Cc, dev, dtype=torch.float32):
+    key = (Cc, dev, dtype)
+    if key not in _ident_bn:
+        t = torch.zeros((4, Cc), device=dev, dtype=dtype)
+        t[0].fill_(1.0)
+        _ident_bn[key] = t
+    return _ident_bn[key]
+
+
+class _SupConFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, features, labels, w1, b1, w2, b2, temperature):
+        v = nhwc(features.detach())
+        N, H, W, Cc = v.shape
+        pooled = ops.colsum(v.reshape(N * H * W, Cc), B=N, scale=1.0 / (H * W))[:, 0, :].contiguous()
+        w1c, w2c = w1.detach().contiguous(), w2.detach().contiguous()
+        h1 = ops.linear(pooled, w1c, b1.detach().contiguous())
+        a1 = ops.bn_act(h1, _identity_bn(h1.shape[1], h1.device, h1.dtype), relu=True)
+        f = ops.linear(a1, w2c, b2.detach().contiguous())
+        loss, dF = ops.contrast_fwd_bwd(f, labels, 1, temperature)
+        ctx.saved = (pooled, a1, dF, w1c, w2c, (N, H, W, Cc))
+        return loss.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pooled, a1, dF, w1c, w2c, (N, H, W, Cc) = ctx.saved
+        ctx.saved = None
+        ops.scale_inplace(dF, _scalar(g))
+        dw2 = torch.empty_like(w2c)
+        ops.linear_wgrad(a1, dF, dw2)
+        db2 = ops.colsum(dF)[0, 0].contiguous()
+        da1 = ops.linear(dF, ops.transpose(w2c))
+        dh1 = ops.relu_bwd(da1, a1)
+        dw1 = torch.empty_like(w1c)
+        ops.linear_wgrad(pooled, dh1, dw1)
+        db1 = ops.colsum(dh1)[0, 0].contiguous()
+        dpool = ops.linear(dh1, ops.transpose(w1c))
+        gfeat = torch.zeros((N, H, W, Cc), device=dF.device, dtype=dF.dtype)
+        ops.add_rowvec_bcast(gfeat, dpool, 1.0 / (H * W))
+        return gfeat.permute(0, 3, 1, 2), None, dw1, db1, dw2, db2, None
+
+
+class SupConLoss(nn.Module):
+    """utils/loss.py:84-205 (Supervised Contrastive / SimCLR on pooled, projected features)."""
+
+    def __init__(self, temperature=0.07, contrast_mode="all", base_temperature=0.07, weight=None, device=None,
+                 opts=None):
+        super().__init__()
+        self.temperature = temperature
+        self.base_temperature = base_temperature
+        self.device = device
+        self.weight = weight
+        self.opts = opts
+        feat_dim = 128
+        dim_in = 2048 if getattr(opts, "deeplab", False) else 128
+        self.avgpool = nn.AdaptiveAvgPool2d((1, 1))
+        self.projection = nn.Sequential(nn.Linear(dim_in, dim_in), nn.ReLU(inplace=True),
+                                        nn.Linear(dim_in, feat_dim)).to(self.device)
+        self.contrast_mode = "all"
+
+    def forward(self, features, class_labels=None, mask=None):
+        if features.dim() != 4:
+            raise ValueError("`features` needs to be [2*bsz, C, H, W]")
+        bsz = features.shape[0] // 2
+        if class_labels is not None and mask is not None:
+            raise ValueError("Cannot define both `labels` and `mask`")
+        if mask is not None:
+            raise NotImplementedError("explicit `mask` is not supported by the HIP SupCon kernel")
+        dev = features.device
+        if class_labels is None:
+            lab = torch.arange(bsz, device=dev, dtype=features.dtype)
+        else:
+            lab = class_labels.contiguous().view(-1).to(dev, features.dtype)
+            if lab.shape[0] != bsz:
+                raise ValueError("Num of labels does not match num of features")
+        lab2 = lab.repeat(2).contiguous()                       # mask.repeat(anchor_count, contrast_count)
+        p = self.projection
+        if self.temperature != self.base_temperature:
+            raise NotImplementedError("temperature != base_temperature")
+        return _SupConFn.apply(features, lab2, p[0].weight, p[0].bias, p[2].weight, p[2].bias,
+                               float(self.temperature))
+
+
+# --------------------------------------------------------------------------- #
+# pixel-level contrastive loss
+# --------------------------------------------------------------------------- #
+class _PixelContrastFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feats, rowidx, y, temperature):
+        v = nhwc(feats.detach())
+        N, H, W, Cc = v.shape
+        X = ops.gather_rows(v.reshape(N * H * W, Cc), rowidx)
+        loss, dX = ops.contrast_fwd_bwd(X, y, 0, temperature)
+        ctx.saved = (dX, rowidx, (N, H, W, Cc))
+        return loss.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        dX, rowidx, (N, H, W, Cc) = ctx.saved
+        ctx.saved = None
+        ops.scale_inplace(dX, _scalar(g))
+        gfeat = torch.zeros((N, H, W, Cc), device=dX.device, dtype=dX.dtype)
+        ops.scatter_add_rows(dX, rowidx, gfeat)
+        return gfeat.permute(0, 3, 1, 2), None, None, None
+
+
+def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):
+    """Host half of utils/loss.py:264-337 given per-(image, class, hard|easy) pixel counts
+    (int tensor [B, C, 2], index 0 = hard, 1 = easy).  Consumes the default CPU generator exactly
+    like the reference (randperm(num_hard) then randperm(num_easy) per kept class).
+
+    Returns None if no class qualifies, else (n_view, T, req [T*n_view, 3], cls [T], img [T]) with
+    req rows (image, key = 2*class + is_easy, rank) in (t, view) order."""
+    B = counts.shape[0]
+    tot = counts.sum(-1)
+    classes = [[c for c in range(num_classes) if int(tot[ii, c]) > max_views] for ii in range(B)]
+    total_classes = sum(len(c) for c in classes)
+    if total_classes == 0:
+        return None
+    n_view = min(max_samples // total_classes, max_views)
+    req: List[List[int]] = []
+    cls: List[int] = []
+    img: List[int] = []
+    for ii in range(B):
+        for c in classes[ii]:
+            num_hard, num_easy = int(counts[ii, c, 0]), int(counts[ii, c, 1])
+            if num_hard >= n_view / 2 and num_easy >= n_view / 2:
+                num_hard_keep = n_view // 2
+                num_easy_keep = n_view - num_hard_keep
+            elif num_hard >= n_view / 2:
+                num_easy_keep = num_easy
+                num_hard_keep = n_view - num_easy_keep
+            elif num_easy >= n_view / 2:
+                num_hard_keep = num_hard
+                num_easy_keep = n_view - num_hard_keep
+            else:
+                print("this shoud be never touched! {} {} {}".format(num_hard, num_easy, n_view))
+                raise Exception
+            perm = torch.randperm(num_hard)
+            for r in perm[:num_hard_keep].tolist():
+                req.append([ii, 2 * c, r])
+            perm = torch.randperm(num_easy)
+            for r in perm[:num_easy_keep].tolist():
+                req.append([ii, 2 * c + 1, r])
+            cls.append(c)
+            img.append(ii)
+    return n_view, total_classes, req, cls, img
+
+
+class PixelContrastLoss(nn.Module, ABC):
+    """utils/loss.py:250-415."""
+
+    def __init__(self, device=None):
+        super().__init__()
+        self.device = device
+        self.temperature = 0.07
+        self.base_temperature = 0.07
+        self.ignore_label = 255
+        self.max_samples = 1024
+        self.max_views = 2
+        self.loss_weight = 1
+        self.contrast_mode = "all"
+        self.last_anchors = None          # (img [T], cls [T], pix [T, n_view]) of the last call, for tests
+
+    def forward(self, feats, labels=None, predict=None):
+        B, Cf, h, w = feats.shape
+        nc = predict.shape[1]
+        assert predict.shape[-1] == feats.shape[-1], "{} {}".format(predict.shape, feats.shape)
+        pl = predict.detach().permute(0, 2, 3, 1)
+        if not (pl.stride(3) == 1 and pl.stride(1) == w * pl.stride(2) and pl.stride(0) == h * w * pl.stride(2)
+                and pl.is_floating_point()):
+            pl = pl.contiguous()
+        cs = pl.stride(2)
+        lab = labels.detach()
+        if lab.dtype != torch.int64 or not lab.is_contiguous():
+            lab = lab.long().contiguous()
+        key, hist = ops.anchor_keys_raw(pl, B, h, w, cs, nc, lab, self.ignore_label)
+        counts = hist.sum(1).view(B, nc, 2).cpu()                 # one D2H sync per step (reference: ~3 per class)
+        plan = plan_anchor_requests(counts, nc, self.max_samples, self.max_views)
+        if plan is None:
+            raise AttributeError("'NoneType' object has no attribute 'shape'")   # loss.py:341 on (None, None)
+        n_view, T, req, cls, img = plan
+        HW = h * w
+        # view-major anchor order of torch.cat(torch.unbind(X_, dim=1)) (loss.py:347): a = v*T + t
+        order = [t * n_view + v for v in range(n_view) for t in range(T)]
+        req_vm = [req[i] for i in order]
+        host = torch.tensor([r + [r[0] * HW] for r in req_vm], dtype=torch.int32)
+        dev = host.to(feats.device, non_blocking=False)
+        pix = ops.anchor_select(key, hist, dev[:, :3].contiguous(), nc)
+        rowidx = (pix + dev[:, 3]).contiguous()
+        y = torch.tensor([float(cls[t]) for _ in range(n_view) for t in range(T)], dtype=feats.dtype).to(feats.device)
+        self.last_anchors = (img, cls, pix.view(n_view, T), n_view)
+        if self.temperature != self.base_temperature:
+            raise NotImplementedError("temperature != base_temperature")
+        return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature))

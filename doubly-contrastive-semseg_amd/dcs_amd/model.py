@@ -1,0 +1,462 @@
+"""Pyramid SwiftNet / ResNet-18 with the reference's module tree and state_dict
+(network/weathernet.py:14-104, network/backbone/resnet_pyramid.py:55-379,
+network/utils.py:35-102), executed by hand-written HIP kernels.
+
+The nn.Module tree below only OWNS parameters and buffers (same names, shapes
+and registration order as the reference, so checkpoints load either way);
+it is never called.  ``SwiftNetEngine`` runs the forward and an explicit
+reverse pass through ``dcs_amd.ops`` and is exposed to autograd as ONE
+``torch.autograd.Function`` whose outputs are the reference's model outputs.
+"""
+from __future__ import annotations
+
+from itertools import chain
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+NUM_FEATURES = 128
+LAYERS = (("layer1", 64, 1), ("layer2", 128, 2), ("layer3", 256, 2), ("layer4", 512, 2))
+LOGIT_CS = 20      # logits are stored NHWC with a channel stride of 20 (19 classes + one zero pad)
+
+
+def _cl(conv: nn.Conv2d) -> nn.Conv2d:
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    return conv
+
+
+def convkxk(inp, out, stride=1, k=3):
+    return _cl(nn.Conv2d(inp, out, kernel_size=k, stride=stride, padding=k // 2, bias=False))
+
+
+class BasicBlock(nn.Module):
+    """Parameter container for resnet_pyramid.py:55-69."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = convkxk(inplanes, planes, stride)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = convkxk(planes, planes)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class _BNReluConv(nn.Sequential):
+    """Parameter container for network/utils.py:35-49."""
+
+    def __init__(self, num_maps_in, num_maps_out, k=3, bias=False):
+        super().__init__()
+        self.add_module("norm", nn.BatchNorm2d(num_maps_in, momentum=0.1))
+        self.add_module("relu", nn.ReLU(inplace=True))
+        self.add_module("conv", _cl(nn.Conv2d(num_maps_in, num_maps_out, kernel_size=k, padding=k // 2, bias=bias)))
+
+
+class _UpsampleBlend(nn.Module):
+    def __init__(self, num_features, k=3):
+        super().__init__()
+        self.blend_conv = _BNReluConv(num_features, num_features, k=k)
+
+
+class ResNetPyramid(nn.Module):
+    """Parameter container for resnet_pyramid.py:130-254 (registration order kept)."""
+
+    def __init__(self, layers=(2, 2, 2, 2), num_features=NUM_FEATURES, mean=(73.15, 82.90, 72.3),
+                 std=(47.67, 48.49, 47.73)):
+        super().__init__()
+        self.inplanes = 64
+        self.conv1 = _cl(nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False))
+        self.register_buffer("img_mean", torch.tensor(mean).view(1, -1, 1, 1))
+        self.register_buffer("img_std", torch.tensor(std).view(1, -1, 1, 1))
+        self.num_features = num_features
+        self.bn1_0 = nn.BatchNorm2d(64)
+        self.bn1_1 = nn.BatchNorm2d(64)
+        self.bn1_2 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.upsample_bottlenecks1 = convkxk(self.inplanes, num_features, k=1)
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.upsample_bottlenecks2 = convkxk(self.inplanes, num_features, k=1)
+        self.layer3 = self._make_layer(256, layers[2], stride=2)
+        self.upsample_bottlenecks3 = convkxk(self.inplanes, num_features, k=1)
+        self.layer4 = self._make_layer(512, layers[3], stride=2)
+        self.upsample_bottlenecks4 = convkxk(self.inplanes, num_features, k=1)
+        self.fine_tune = [self.conv1, self.maxpool, self.layer1, self.layer2, self.layer3, self.layer4,
+                          self.bn1_0, self.bn1_1, self.bn1_2]
+        for i in range(1, 6):
+            setattr(self, f"upsample_blends{i}", _UpsampleBlend(num_features, k=3))
+        self.random_init = [self.upsample_bottlenecks1, self.upsample_bottlenecks2, self.upsample_bottlenecks3,
+                            self.upsample_bottlenecks4] + [getattr(self, f"upsample_blends{i}") for i in range(1, 6)]
+        self.features = num_features
+        for m in self.modules():                      # resnet_pyramid.py:249-254
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes:
+            downsample = nn.Sequential(
+                _cl(nn.Conv2d(self.inplanes, planes, kernel_size=1, stride=stride, bias=False)),
+                nn.BatchNorm2d(planes))
+        layers = [BasicBlock(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes
+        for _ in range(1, blocks):
+            layers.append(BasicBlock(self.inplanes, planes))
+        return nn.Sequential(*layers)
+
+    def random_init_params(self):
+        return chain(*[f.parameters() for f in self.random_init])
+
+    def fine_tune_params(self):
+        return chain(*[f.parameters() for f in self.fine_tune])
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                              error_msgs):
+        """ImageNet ResNet checkpoints carry one ``bn1.*``; fan it out to the three per-level stem
+        BNs like resnet_pyramid.py:381-393."""
+        super()._load_from_state_dict(state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys,
+                                      error_msgs)
+        if any(k.startswith(prefix + "bn1.") for k in state_dict):
+            for bn in (self.bn1_0, self.bn1_1, self.bn1_2):
+                bn._load_from_state_dict(state_dict, prefix + "bn1.", local_metadata, False, [], [], error_msgs)
+
+
+# --------------------------------------------------------------------------- #
+class _Saved:
+    __slots__ = ("tape", "shapes", "training", "B", "Bm")
+
+
+class SwiftNetEngine:
+    """Forward + explicit backward of the pyramid SwiftNet on HIP kernels."""
+
+    def __init__(self, fe: ResNetPyramid, seg: Optional[_BNReluConv], num_classes: int):
+        self.fe, self.seg, self.num_classes = fe, seg, num_classes
+        self._mean = self._std = None
+
+    # ---- helpers ---------------------------------------------------------
+    def _bn(self, x, m: nn.BatchNorm2d, training, rows=None):
+        Cc = x.shape[-1]
+        rows = rows if rows is not None else x.numel() // Cc
+        if training:
+            sums = ops.colsum(x.reshape(-1, Cc)[:rows])
+            bn = ops.bn_finalize(sums, m.weight, m.bias, m.running_mean, m.running_var, rows, True,
+                                 momentum=m.momentum)
+            self._nbt.append(m)
+            return bn
+        return ops.bn_finalize(None, m.weight, m.bias, m.running_mean, m.running_var, rows, False)
+
+    def _flush_nbt(self):
+        for m in self._nbt:
+            m.num_batches_tracked += 1          # host-side scalar bookkeeping (not on the data path)
+        self._nbt = []
+
+    # ---- forward ---------------------------------------------------------
+    def forward(self, img, training: bool, supcon: bool, need_grad: bool):
+        fe = self.fe
+        self._mean = fe.img_mean.reshape(3).contiguous()
+        self._std = fe.img_std.reshape(3).contiguous()
+        self._nbt = []
+        tape: List[tuple] = [] if need_grad else None
+        Bm, _, H, W = img.shape
+        pyr = ops.normalize_pyramid(img if img.is_floating_point() else img.float(), self._mean, self._std)
+        wst = ops.pack_stem_weight(fe.conv1.weight)
+        skips: List[List[torch.Tensor]] = [[] for _ in range(6)]
+        for idx, p in enumerate(pyr):
+            y = ops.stem_conv(p, wst)
+            bnm = getattr(fe, f"bn1_{idx}")
+            bn = self._bn(y, bnm, training)
+            x, pidx = ops.bn_relu_maxpool(y, bn)
+            if need_grad:
+                tape.append(("stem", idx, p, y, bn, pidx, bnm))
+            for li, (lname, planes, stride) in enumerate(LAYERS):
+                for blk in getattr(fe, lname):
+                    x = self._block_fwd(x, blk, training, tape)
+                bott = getattr(fe, f"upsample_bottlenecks{li + 1}")
+                s = ops.conv_fwd(x, bott.weight, 1, 0)
+                if need_grad:
+                    tape.append(("skip", idx + li, x, bott))
+                skips[idx + li].append(s)
+        skips = skips[::-1]
+        x = skips[0][0]
+        for i in range(1, 6):
+            blend = getattr(fe, f"upsample_blends{i}").blend_conv
+            sk = skips[i]
+            OH, OW = sk[0].shape[1:3]
+            t = ops.upsample_add(x, sk, OH, OW)
+            bn = self._bn(t, blend.norm, training)
+            z = ops.bn_act(t, bn, relu=True)
+            xn = ops.conv_fwd(z, blend.conv.weight, 1, 1)
+            if need_grad:
+                tape.append(("blend", i, x.shape[1:3], t, bn, z, blend))
+            x = xn
+        fine_feat = x
+        B = Bm // 2 if supcon else Bm
+        seg = before = None
+        if self.seg is not None:
+            h, w = fine_feat.shape[1:3]
+            ff0 = fine_feat[:B]
+            bnh = self._bn(ff0, self.seg.norm, training, rows=B * h * w)
+            zh = ops.bn_act(ff0, bnh, relu=True)
+            before = ops.conv_fwd(zh, self.seg.conv.weight, 1, 0, bias=self.seg.conv.bias, dst_cs=LOGIT_CS)
+            seg = ops.upsample_to_nchw(before, self.num_classes, H, W)
+            if need_grad:
+                tape.append(("head", ff0, bnh, zh, (H, W)))
+        self._flush_nbt()
+        saved = None
+        if need_grad:
+            saved = _Saved()
+            saved.tape, saved.training, saved.B, saved.Bm = tape, training, B, Bm
+        return seg, before, fine_feat, saved
+
+    def _block_fwd(self, x, blk: BasicBlock, training, tape):
+        s = blk.stride
+        y1 = ops.conv_fwd(x, blk.conv1.weight, s, 1)
+        bn1 = self._bn(y1, blk.bn1, training)
+        z1 = ops.bn_act(y1, bn1, relu=True)
+        y2 = ops.conv_fwd(z1, blk.conv2.weight, 1, 1)
+        bn2 = self._bn(y2, blk.bn2, training)
+        yd = bnd = None
+        if blk.downsample is not None:
+            yd = ops.conv_fwd(x, blk.downsample[0].weight, s, 0)
+            bnd = self._bn(yd, blk.downsample[1], training)
+            out = ops.bn_act(y2, bn2, r=yd, bn2=bnd, relu=True)
+        else:
+            out = ops.bn_act(y2, bn2, r=x, relu=True)
+        if tape is not None:
+            tape.append(("block", blk, x, y1, bn1, z1, y2, bn2, yd, bnd, out))
+        return out
+
+    # ---- backward --------------------------------------------------------
+    def backward(self, saved: _Saved, g_seg, g_before, g_ff) -> Dict[nn.Parameter, torch.Tensor]:
+        """Returns {parameter: gradient}.  g_seg NCHW [B,C,H,W]; g_before NHWC [B,h,w,LOGIT_CS] or None;
+        g_ff NHWC [Bm,h,w,128] or None (external gradient of fine_feat; consumed/modified)."""
+        grads: Dict[nn.Parameter, torch.Tensor] = {}
+        packed: Dict[nn.Parameter, torch.Tensor] = {}
+        training = saved.training
+
+        def wgrad(conv, x, dy, stride, pad):
+            w = conv.weight
+            acc = w in grads
+            if not acc:
+                grads[w] = torch.empty_like(w)
+            ops.conv_wgrad(x, dy, grads[w], stride, pad, acc)
+
+        def wp(conv):
+            w = conv.weight
+            if w not in packed:
+                packed[w] = ops.pack_dgrad_weight(w)
+            return packed[w]
+
+        def bn_bwd(m: nn.BatchNorm2d, g, y, bn, **kw):
+            acc = m.weight in grads
+            if not acc:
+                grads[m.weight] = torch.empty_like(m.weight)
+                grads[m.bias] = torch.empty_like(m.bias)
+            return ops.bn_bwd(g, y, bn, m.weight, dgamma=grads[m.weight], dbeta=grads[m.bias], acc_param=acc, **kw)
+
+        tape = saved.tape
+        pos = len(tape) - 1
+        g_x = None                     # gradient of the decoder tensor flowing down
+        g_skip: Dict[int, torch.Tensor] = {}
+        # ---- head ----
+        if tape[pos][0] == "head":
+            _, ff0, bnh, zh, (H, W) = tape[pos]
+            pos -= 1
+            B, h, w, _ = ff0.shape
+            gb = None
+            if g_seg is not None:
+                gb = ops.upsample_to_nchw_bwd(g_seg, h, w, LOGIT_CS)
+            if g_before is not None:
+                if gb is None:
+                    gb = g_before.contiguous()
+                else:
+                    ops.axpy(gb, g_before.contiguous(), 1.0)
+            if gb is not None:
+                seg = self.seg
+                wgrad(seg.conv, zh, gb, 1, 0)
+                bsum = ops.colsum(gb.reshape(-1, LOGIT_CS))
+                grads[seg.conv.bias] = bsum[0, 0, :self.num_classes].clone()
+                wpad = torch.zeros((NUM_FEATURES, 1, 1, LOGIT_CS), device=gb.device, dtype=gb.dtype)
+                wpad[..., :self.num_classes] = wp(seg.conv)
+                g_zh = ops.conv_dgrad(gb, wpad, (h, w), 1, 0)
+                if g_ff is None and saved.Bm == B:
+                    g_ff, _ = bn_bwd(seg.norm, g_zh, ff0, bnh, relu=True)
+                else:
+                    if g_ff is None:
+                        g_ff = torch.zeros((saved.Bm, h, w, NUM_FEATURES), device=gb.device, dtype=gb.dtype)
+                    bn_bwd(seg.norm, g_zh, ff0, bnh, relu=True, dy_out=g_ff[:B], acc_dy=True)
+        if g_ff is None:
+            raise RuntimeError("backward called without any gradient")
+        g_x = g_ff
+        # ---- decoder ----
+        while pos >= 0 and tape[pos][0] == "blend":
+            _, i, in_hw, t, bn, z, blend = tape[pos]
+            pos -= 1
+            wgrad(blend.conv, z, g_x, 1, 1)
+            g_z = ops.conv_dgrad(g_x, wp(blend.conv), t.shape[1:3], 1, 1)
+            g_t, _ = bn_bwd(blend.norm, g_z, t, bn, relu=True)
+            g_skip[5 - i] = g_t                      # skips[idx + li] with idx + li = 5 - i
+            g_x = ops.upsample_bwd(g_t, in_hw[0], in_hw[1])
+        g_skip[5] = g_x                              # coarsest map: level 2, layer4
+        # ---- encoder, pyramid levels in reverse creation order ----
+        g_cur = None
+        dwst = None
+        while pos >= 0:
+            item = tape[pos]
+            pos -= 1
+            kind = item[0]
+            if kind == "skip":
+                _, lvl, x, bott = item
+                gs = g_skip[lvl]
+                wgrad(bott, x, gs, 1, 0)
+                if g_cur is None:
+                    g_cur = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0)
+                else:
+                    ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, out=g_cur, accumulate=True)
+            elif kind == "block":
+                _, blk, x, y1, bn1, z1, y2, bn2, yd, bnd, out = item
+                s = blk.stride
+                dy2, gm = bn_bwd(blk.bn2, g_cur, y2, bn2, masksrc=out, want_gm=True)
+                ops.bn_ema_again(bn2, blk.bn2.running_mean, blk.bn2.running_var, y2.numel() // y2.shape[-1],
+                                 momentum=blk.bn2.momentum)
+                self._nbt.append(blk.bn2)
+                wgrad(blk.conv2, z1, dy2, 1, 1)
+                g_z1 = ops.conv_dgrad(dy2, wp(blk.conv2), z1.shape[1:3], 1, 1)
+                dy1, _ = bn_bwd(blk.bn1, g_z1, y1, bn1, relu=True)
+                ops.bn_ema_again(bn1, blk.bn1.running_mean, blk.bn1.running_var, y1.numel() // y1.shape[-1],
+                                 momentum=blk.bn1.momentum)
+                self._nbt.append(blk.bn1)
+                wgrad(blk.conv1, x, dy1, s, 1)
+                if blk.downsample is not None:
+                    dyd, _ = bn_bwd(blk.downsample[1], gm, yd, bnd)
+                    wgrad(blk.downsample[0], x, dyd, s, 0)
+                    g_in = ops.conv_dgrad(dyd, wp(blk.downsample[0]), x.shape[1:3], s, 0)
+                else:
+                    g_in = gm
+                ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1, out=g_in, accumulate=True)
+                g_cur = g_in
+            elif kind == "stem":
+                _, idx, p, y, bn, pidx, bnm = item
+                gz = ops.maxpool_bwd(g_cur, pidx, y.shape[1], y.shape[2])
+                dy, _ = bn_bwd(bnm, gz, y, bn, relu=True)
+                if dwst is None:
+                    dwst = torch.empty((64, 7, 8, 4), device=dy.device, dtype=dy.dtype)
+                    ops.stem_wgrad(p, dy, dwst, False)
+                else:
+                    ops.stem_wgrad(p, dy, dwst, True)
+                g_cur = None
+            else:  # pragma: no cover
+                raise RuntimeError(kind)
+        if dwst is not None:
+            grads[self.fe.conv1.weight] = ops.unpack_stem_weight(dwst, self.fe.conv1.weight)
+        self._flush_nbt()
+        return grads
+
+
+class _SwiftNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine: SwiftNetEngine, img, training, supcon, grad_enabled, *params):
+        need_grad = grad_enabled and any(p.requires_grad for p in params)
+        ctx.set_materialize_grads(False)
+        seg, before, ff, saved = engine.forward(img, training, supcon, need_grad)
+        ctx.engine, ctx.saved, ctx.params = engine, saved, params
+        outs = [t if t is not None else img.new_zeros(1) for t in (seg, before, ff)]
+        ctx.has = [t is not None for t in (seg, before, ff)]
+        ctx.mark_non_differentiable(*[o for o, h in zip(outs, ctx.has) if not h])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_seg, g_before, g_ff):
+        if ctx.saved is None:
+            raise RuntimeError("SwiftNet backward without a recorded forward")
+        if g_ff is not None:
+            g_ff = g_ff.contiguous().clone() if g_ff.is_contiguous() else g_ff.contiguous()
+        if g_seg is not None:
+            g_seg = g_seg.contiguous()
+        grads = ctx.engine.backward(ctx.saved, g_seg if ctx.has[0] else None,
+                                    g_before if (ctx.has[1] and g_before is not None) else None, g_ff)
+        ctx.saved = None
+        return (None, None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+class WeatherNet(nn.Module):
+    """Drop-in for network.WeatherNet (network/weathernet.py:14-104): same constructor, same
+    4-tuple forward, same state_dict; ``backbone`` must be 'resnet18'."""
+
+    def __init__(self, opts, num_downsample=2, num_classes=19, device=None, feature_similarity="correlation",
+                 aggregation_type="adaptive", num_scales=3, backbone="resnet34", train_semantic=True):
+        super().__init__()
+        self.opts = opts
+        self.num_downsample = num_downsample
+        self.aggregation_type = aggregation_type
+        self.num_scales = num_scales
+        self.num_classes = num_classes
+        self.device = device
+        if backbone == "resnet18":
+            self.feature_extractor = ResNetPyramid((2, 2, 2, 2))
+        elif backbone == "resnet34":
+            self.feature_extractor = ResNetPyramid((3, 4, 6, 3))
+        else:
+            raise NotImplementedError
+        self.segmentation = None
+        if train_semantic:
+            self.segmentation = _BNReluConv(self.feature_extractor.num_features, self.num_classes, k=1, bias=True)
+            self.loss_ret_additional = False
+            self.img_req_grad = False
+            self.upsample_logits = True
+            self.multiscale_factors = (.5, .75, 1.5, 2.)
+        self._engine = None
+
+    def _get_engine(self):
+        if self._engine is None:
+            object.__setattr__(self, "_engine", SwiftNetEngine(self.feature_extractor, self.segmentation,
+                                                               self.num_classes))
+        return self._engine
+
+    def forward(self, left_img, return_supcon_feature=False):
+        ops.require_device(left_img, "left_img")
+        params = [p for p in self.parameters()]
+        seg, before, ff = _SwiftNetFn.apply(self._get_engine(), left_img, self.training,
+                                            bool(return_supcon_feature), torch.is_grad_enabled(), *params)
+        # NHWC buffers exposed with the reference's logical NCHW shapes (channels_last strides, no copy)
+        fine_feat = ff.permute(0, 3, 1, 2)
+        if return_supcon_feature:
+            bsz = fine_feat.shape[0] // 2
+            fine_feat0 = torch.split(fine_feat, [bsz, bsz], dim=0)[0]
+        else:
+            fine_feat0 = fine_feat
+        if self.segmentation is None:
+            return None, None, fine_feat, fine_feat0
+        pred_segmap_beforeup = before[..., :self.num_classes].permute(0, 3, 1, 2)
+        return seg, pred_segmap_beforeup, fine_feat, fine_feat0
+
+    def random_init_params(self):
+        return self.feature_extractor.random_init_params()
+
+    def fine_tune_params(self):
+        return self.feature_extractor.fine_tune_params()
+
+
+class WeatherClassifier(nn.Module):
+    """Drop-in for network.WeatherClassifier (network/classifier.py:6-32): GAP + Linear."""
+
+    def __init__(self, opts, weather_class_num):
+        super().__init__()
+        self.opts = opts
+        num_channels = 2048 if getattr(opts, "deeplab", False) else 128
+        self.pool_attention = nn.AdaptiveAvgPool2d((1, 1))
+        self.fc = nn.Linear(num_channels, weather_class_num)
+
+    def forward(self, x):
+        from .losses import global_avg_pool
+        pooled = global_avg_pool(x)                  # HIP reduction, [B, C]
+        return ops.linear(pooled.detach().contiguous(), self.fc.weight.detach().contiguous(),
+                          self.fc.bias.detach().contiguous())

@@ -1,0 +1,511 @@
+"""Tensor-level wrappers over the C ABI (include/dcs_hip.h).
+
+PyTorch supplies device memory and the current HIP stream only; every
+computation below is a kernel of libdcs_hip.so.  Activations are 4-D
+``[N, H, W, C]`` contiguous fp32 tensors (NHWC), convolution weights are the
+reference's OIHW parameters held in channels_last memory format (= KRSC).
+All functions require CUDA(HIP) tensors; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _lib
+from .lib import DcsConvGeom
+
+_F32 = torch.float32
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _call(name: str, *args):
+    rc = getattr(_lib.load(), name)(*args)
+    if rc != 0:
+        _lib.check(rc, name)
+
+
+def _req(t: torch.Tensor, dtype=_F32):
+    if not t.is_cuda or t.dtype != dtype or not t.is_contiguous():
+        raise RuntimeError(f"dcs_amd.ops needs contiguous {dtype} device tensors, got {t.device} {t.dtype} "
+                           f"contiguous={t.is_contiguous()} (no CPU fallback)")
+    return t
+
+
+def require_device(t: torch.Tensor, what="input"):
+    """The product path runs on the GPU only; a CPU tensor is an error, never a fallback."""
+    if not t.is_cuda:
+        raise RuntimeError(f"dcs_amd runs on MI355X only (no CPU path): {what} is a CPU tensor")
+
+
+def krsc(w: torch.Tensor) -> torch.Tensor:
+    """[Cout,R,S,Cin] contiguous view of an OIHW channels_last parameter (no copy)."""
+    v = w.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise RuntimeError("convolution weights must be in channels_last memory format")
+    return v
+
+
+# --------------------------------------------------------------------------- #
+# geometry (cached per shape)
+# --------------------------------------------------------------------------- #
+_geom_cache = {}
+
+
+def _mk_geom(N, SH, SW, DH, DW, TY, TX, sy, dsy, dy0, dx0, K, Cout, taps, wstride, src_cs, dst_cs, stem=0):
+    g = DcsConvGeom()
+    g.N, g.SH, g.SW, g.DH, g.DW, g.TY, g.TX = N, SH, SW, DH, DW, TY, TX
+    g.sy = g.sx = sy
+    g.dsy = g.dsx = dsy
+    g.dy0, g.dx0 = dy0, dx0
+    g.K, g.Cout, g.ntaps, g.wstride = K, Cout, len(taps), wstride
+    g.src_cstride, g.dst_cstride, g.stem = src_cs, dst_cs, stem
+    for i, (oy, ox, wo) in enumerate(taps):
+        g.offy[i], g.offx[i], g.wofs[i] = oy, ox, wo
+    return g
+
+
+def out_size(n, k, stride, pad):
+    return (n + 2 * pad - k) // stride + 1
+
+
+def geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, src_cs=None, dst_cs=None):
+    key = ("f", N, H, W, Cin, Cout, R, S, stride, pad, src_cs, dst_cs)
+    g = _geom_cache.get(key)
+    if g is None:
+        OH, OW = out_size(H, R, stride, pad), out_size(W, S, stride, pad)
+        taps = [(r - pad, s - pad, (r * S + s) * Cin) for r in range(R) for s in range(S)]
+        g = _mk_geom(N, H, W, OH, OW, OH, OW, stride, 1, 0, 0, Cin, Cout, taps, R * S * Cin,
+                     src_cs or Cin, dst_cs or Cout)
+        _geom_cache[key] = g
+    return g
+
+
+def geoms_dgrad(N, IH, IW, Cin, Cout, R, S, stride, pad):
+    """One geometry per input parity class (no wasted taps for stride 2)."""
+    key = ("d", N, IH, IW, Cin, Cout, R, S, stride, pad)
+    gs = _geom_cache.get(key)
+    if gs is None:
+        OH, OW = out_size(IH, R, stride, pad), out_size(IW, S, stride, pad)
+        gs = []
+        for py in range(stride):
+            for px in range(stride):
+                TY, TX = -(-(IH - py) // stride), -(-(IW - px) // stride)
+                if TY <= 0 or TX <= 0:
+                    continue
+                taps = [((py + pad - r) // stride, (px + pad - s) // stride, (r * S + s) * Cout)
+                        for r in range(R) for s in range(S)
+                        if (py + pad - r) % stride == 0 and (px + pad - s) % stride == 0]
+                if not taps:
+                    gs.append(None)
+                    continue
+                gs.append(_mk_geom(N, OH, OW, IH, IW, TY, TX, 1, stride, py, px, Cout, Cin, taps, R * S * Cout,
+                                   Cout, Cin))
+        _geom_cache[key] = gs
+    return gs
+
+
+def geom_stem(N, H, W):
+    key = ("s", N, H, W)
+    g = _geom_cache.get(key)
+    if g is None:
+        OH, OW = out_size(H, 7, 2, 3), out_size(W, 7, 2, 3)
+        taps = [(r - 3, -3, r * 32) for r in range(7)]
+        g = _mk_geom(N, H, W, OH, OW, OH, OW, 2, 1, 0, 0, 4, 64, taps, 224, 4, 64, stem=1)
+        _geom_cache[key] = g
+    return g
+
+
+# --------------------------------------------------------------------------- #
+# convolution
+# --------------------------------------------------------------------------- #
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None):
+    """nn.Conv2d forward.  x [N,H,W,Cin]; w OIHW channels_last; -> [N,OH,OW,dst_cs or Cout]."""
+    _req(x)
+    N, H, W, Cin = x.shape
+    Cout, _, R, S = w.shape
+    g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, None, dst_cs)
+    cs = dst_cs or Cout
+    alloc = torch.zeros if cs != Cout else torch.empty
+    y = alloc((N, g.DH, g.DW, cs), device=x.device, dtype=_F32)
+    _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, _stream())
+    return y
+
+
+def pack_dgrad_weight(w):
+    """[Cout,R,S,Cin] -> [Cin,R,S,Cout] for the data-gradient GEMM."""
+    Cout, Cin, R, S = w.shape
+    o = torch.empty((Cin, R, S, Cout), device=w.device, dtype=_F32)
+    _call("dcs_pack_dgrad_weight", _p(krsc(w)), _p(o), Cout, R, S, Cin, _stream())
+    return o
+
+
+def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None):
+    """Data gradient.  dy [N,OH,OW,cs>=Cout]; wp = pack_dgrad_weight(w) [Cin,R,S,Cout]."""
+    _req(dy)
+    N = dy.shape[0]
+    Cin, R, S, Cout = wp.shape
+    IH, IW = in_hw
+    gs = geoms_dgrad(N, IH, IW, Cin, Cout, R, S, stride, pad)
+    if out is None:
+        accumulate = False
+        out = (torch.zeros if any(g is None for g in gs) else torch.empty)((N, IH, IW, Cin), device=dy.device, dtype=_F32)
+    elif not accumulate and any(g is None for g in gs):
+        out.zero_()
+    cs = dy.shape[3]
+    for g in gs:
+        if g is None:
+            continue
+        if cs != g.src_cstride:
+            g = _with_src_cs(g, cs)
+        _call("dcs_conv_gather", _p(dy), _p(wp), None, _p(out), C.byref(g), 1 if accumulate else 0, _stream())
+    return out
+
+
+def _with_src_cs(g, cs):
+    key = ("cs", id(g), cs)
+    h = _geom_cache.get(key)
+    if h is None:
+        h = DcsConvGeom()
+        C.memmove(C.byref(h), C.byref(g), C.sizeof(DcsConvGeom))
+        h.src_cstride = cs
+        _geom_cache[key] = h
+        _geom_cache[("keep", id(g))] = g
+    return h
+
+
+def _nsplit(tiles, M):
+    return max(1, min(-(-1024 // tiles), -(-M // 256)))
+
+
+def conv_wgrad(x, dy, dw, stride, pad, accumulate):
+    """Weight gradient into dw (OIHW channels_last, same layout as the parameter)."""
+    _req(x), _req(dy)
+    N, H, W, Cin = x.shape
+    Cout, _, R, S = dw.shape
+    g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad)
+    M = N * g.DH * g.DW
+    bt = 128 if (Cout > 64 and Cin > 64) else 64
+    tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
+    ns = _nsplit(tiles, M)
+    n = Cout * R * S * Cin
+    slab = torch.empty((ns, n), device=x.device, dtype=_F32)
+    _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())
+    _call("dcs_reduce_slab", _p(slab), _p(krsc(dw)), n, ns, 1 if accumulate else 0, _stream())
+
+
+def pack_stem_weight(w):
+    o = torch.empty((w.shape[0], 7, 8, 4), device=w.device, dtype=_F32)
+    _call("dcs_pack_stem_weight", _p(krsc(w)), _p(o), w.shape[0], 0, _stream())
+    return o
+
+
+def unpack_stem_weight(wp, like):
+    o = torch.empty_like(like)           # preserves channels_last
+    _call("dcs_pack_stem_weight", _p(wp), _p(krsc(o)), wp.shape[0], 1, _stream())
+    return o
+
+
+def stem_conv(p, wp):
+    """7x7/2 pad 3 conv on the NHWC4 normalised image; wp = pack_stem_weight(conv1.weight)."""
+    _req(p)
+    N, H, W, _ = p.shape
+    g = geom_stem(N, H, W)
+    y = torch.empty((N, g.DH, g.DW, 64), device=p.device, dtype=_F32)
+    _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, _stream())
+    return y
+
+
+def stem_wgrad(p, dy, dwp, accumulate):
+    """Accumulates the packed stem weight gradient dwp [64,7,8,4]."""
+    N, H, W, _ = p.shape
+    g = geom_stem(N, H, W)
+    M = N * g.DH * g.DW
+    ns = _nsplit(7, M)
+    slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
+    _call("dcs_conv_wgrad", _p(p), _p(dy), _p(slab), C.byref(g), 64, 0, ns, _stream())
+    _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, _stream())
+
+
+def linear(x, w, bias=None):
+    """y = x w^T + b as a 1x1 convolution.  x [rows, K]; w [Cout, K] contiguous."""
+    rows, K = x.shape
+    Cout = w.shape[0]
+    g = geom_fwd(rows, 1, 1, K, Cout, 1, 1, 1, 0)
+    y = torch.empty((rows, Cout), device=x.device, dtype=_F32)
+    _call("dcs_conv_gather", _p(_req(x)), _p(_req(w)), _p(bias), _p(y), C.byref(g), 0, _stream())
+    return y
+
+
+def transpose(x):
+    R, Cc = x.shape
+    o = torch.empty((Cc, R), device=x.device, dtype=_F32)
+    _call("dcs_transpose", _p(_req(x)), _p(o), R, Cc, _stream())
+    return o
+
+
+def linear_wgrad(x, dy, dw, accumulate=False):
+    """dw [Cout,K] (+)= dy^T x."""
+    rows, K = x.shape
+    Cout = dy.shape[1]
+    g = geom_fwd(rows, 1, 1, K, Cout, 1, 1, 1, 0)
+    ns = 1
+    slab = torch.empty((ns, Cout * K), device=x.device, dtype=_F32)
+    _call("dcs_conv_wgrad", _p(_req(x)), _p(_req(dy)), _p(slab), C.byref(g), Cout, 0, ns, _stream())
+    _call("dcs_reduce_slab", _p(slab), _p(dw), Cout * K, ns, 1 if accumulate else 0, _stream())
+
+
+# --------------------------------------------------------------------------- #
+# reductions / BatchNorm
+# --------------------------------------------------------------------------- #
+def _groups(rows):
+    return int(max(1, min(1024, rows // 64)))
+
+
+def colsum(x2d, B=1, scale=1.0):
+    """x2d [B*rows, C(strided)] -> sums [B,2,C] (sum, sum of squares) * scale."""
+    _req(x2d)
+    total, Cc = x2d.shape
+    rows = total // B
+    grp = _groups(rows)
+    part = torch.empty((B, grp, 2, Cc), device=x2d.device, dtype=_F32)
+    _call("dcs_colsum_partial", _p(x2d), None, None, None, _p(part), B, rows, Cc, Cc, grp, 0, 0, _stream())
+    out = torch.empty((B, 2, Cc), device=x2d.device, dtype=_F32)
+    _call("dcs_colsum_final", _p(part), _p(out), B, grp, Cc, float(scale), _stream())
+    return out
+
+
+def bn_finalize(sums, gamma, beta, rm, rv, count, training, repeats=1, eps=1e-5, momentum=0.1, update=True):
+    Cc = gamma.shape[0]
+    bn = torch.empty((4, Cc), device=gamma.device, dtype=_F32)
+    upd = training and update
+    _call("dcs_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(rm) if (upd or not training) else None,
+          _p(rv) if (upd or not training) else None, _p(bn), Cc, float(count), eps, momentum, repeats,
+          1 if training else 0, _stream())
+    return bn
+
+
+def bn_ema_again(bn, rm, rv, count, eps=1e-5, momentum=0.1):
+    _call("dcs_bn_ema_again", _p(bn), _p(rm), _p(rv), rm.shape[0], float(count), eps, momentum, _stream())
+
+
+def bn_act(y, bn, r=None, bn2=None, relu=True):
+    _req(y)
+    z = torch.empty_like(y)
+    Cc = y.shape[-1]
+    _call("dcs_bn_act", _p(y), _p(bn), _p(r), _p(bn2), _p(z), y.numel() // Cc, Cc, 1 if relu else 0, _stream())
+    return z
+
+
+def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=False, dy_out=None, acc_dy=False,
+           dgamma=None, dbeta=None, acc_param=False):
+    """BatchNorm (+ReLU mask) backward.  Returns (dy, gm).  dgamma/dbeta are written (or accumulated)."""
+    _req(g), _req(y)
+    Cc = y.shape[-1]
+    rows = y.numel() // Cc
+    grp = _groups(rows)
+    part = torch.empty((1, grp, 2, Cc), device=y.device, dtype=_F32)
+    _call("dcs_colsum_partial", _p(g), _p(y), _p(masksrc), _p(bn), _p(part), 1, rows, Cc, Cc, grp, 1,
+          1 if relu else 0, _stream())
+    sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
+    _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, _stream())
+    dy = None
+    if want_dy:
+        dy = dy_out if dy_out is not None else torch.empty_like(y)
+    gm = torch.empty_like(y) if want_gm else None
+    _call("dcs_bn_bwd_apply", _p(g), _p(y), _p(masksrc), _p(bn), _p(gamma), _p(sums), _p(dy), _p(gm), _p(dgamma),
+          _p(dbeta), rows, Cc, 1 if relu else 0, 1 if (acc_dy and dy_out is not None) else 0, 0,
+          1 if acc_param else 0, _stream())
+    return dy, gm
+
+
+# --------------------------------------------------------------------------- #
+# pyramid / pooling / resize
+# --------------------------------------------------------------------------- #
+def normalize_pyramid(img, mean3, std3):
+    if not img.is_cuda or img.dtype != _F32:
+        raise RuntimeError("normalize_pyramid needs an fp32 device tensor")
+    img = img.contiguous()
+    N, Cc, H, W = img.shape
+    assert Cc == 3
+    mk = lambda h, w: torch.empty((N, h, w, 4), device=img.device, dtype=_F32)
+    p0, p1, p2 = mk(H, W), mk(H // 2, W // 2), mk(H // 4, W // 4)
+    _call("dcs_normalize_pyramid", _p(img), _p(p0), _p(p1), _p(p2), N, H, W, _p(mean3), _p(std3), _stream())
+    return p0, p1, p2
+
+
+def bn_relu_maxpool(y, bn):
+    N, H, W, Cc = y.shape
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = torch.empty((N, OH, OW, Cc), device=y.device, dtype=_F32)
+    idx = torch.empty((N, OH, OW, Cc), device=y.device, dtype=torch.uint8)
+    _call("dcs_bn_relu_maxpool", _p(_req(y)), _p(bn), _p(out), _p(idx), N, H, W, Cc, _stream())
+    return out, idx
+
+
+def maxpool_bwd(g, idx, H, W):
+    N, _, _, Cc = g.shape
+    gz = torch.empty((N, H, W, Cc), device=g.device, dtype=_F32)
+    _call("dcs_maxpool_bwd", _p(_req(g)), _p(idx), _p(gz), N, H, W, Cc, _stream())
+    return gz
+
+
+def upsample_add(x, skips: Sequence[torch.Tensor], OH, OW):
+    N, IH, IW, Cc = x.shape
+    t = torch.empty((N, OH, OW, Cc), device=x.device, dtype=_F32)
+    s = list(skips) + [None] * (3 - len(skips))
+    _call("dcs_upsample_add", _p(_req(x)), _p(s[0]), _p(s[1]), _p(s[2]), _p(t), N, IH, IW, OH, OW, Cc, _stream())
+    return t
+
+
+def upsample_bwd(g, IH, IW, out=None, accumulate=False):
+    N, OH, OW, Cc = g.shape
+    if out is None:
+        out = torch.empty((N, IH, IW, Cc), device=g.device, dtype=_F32)
+        accumulate = False
+    _call("dcs_upsample_bwd", _p(_req(g)), _p(out), N, IH, IW, OH, OW, Cc, 1 if accumulate else 0, _stream())
+    return out
+
+
+def upsample_to_nchw(x, Cc, OH, OW):
+    N, IH, IW, cs = x.shape
+    out = torch.empty((N, Cc, OH, OW), device=x.device, dtype=_F32)
+    _call("dcs_upsample_to_nchw", _p(_req(x)), _p(out), N, IH, IW, cs, Cc, OH, OW, _stream())
+    return out
+
+
+def upsample_to_nchw_bwd(g, IH, IW, cs, gscale=None):
+    N, Cc, OH, OW = g.shape
+    gx = torch.empty((N, IH, IW, cs), device=g.device, dtype=_F32)
+    _call("dcs_upsample_to_nchw_bwd", _p(_req(g)), _p(gscale), _p(gx), N, IH, IW, cs, Cc, OH, OW, _stream())
+    return gx
+
+
+# --------------------------------------------------------------------------- #
+# losses
+# --------------------------------------------------------------------------- #
+SEG_MODES = {"full": 0, "plain_focal": 1, "no_class_weights": 2, "no_EDT": 3, "ce": 4}
+
+
+def seg_loss(logits, target, ldw, cw, mode, gamma=0.5, ignore=255):
+    """Returns (out[3] = loss, count, 1/count ; grad = unscaled d(sum loss)/d logits)."""
+    _req(logits)
+    if target.dtype != torch.int64 or not target.is_contiguous() or not target.is_cuda:
+        raise RuntimeError("seg_loss: target must be a contiguous int64 device tensor")
+    N, Cc, H, W = logits.shape
+    grad = torch.empty_like(logits)
+    blocks = int(max(1, min(4096, (N * H * W + 255) // 256)))
+    part = torch.empty((blocks, 2), device=logits.device, dtype=_F32)
+    out = torch.empty((3,), device=logits.device, dtype=_F32)
+    _call("dcs_seg_loss", _p(logits), _p(target), _p(ldw), _p(cw), _p(grad), _p(part), N, Cc, H, W,
+          SEG_MODES[mode], float(gamma), int(ignore), blocks, _stream())
+    _call("dcs_seg_loss_final", _p(part), _p(out), blocks, _stream())
+    return out, grad
+
+
+def scale_inplace(x, a, b=None):
+    _call("dcs_scale_inplace", _p(x), x.numel(), _p(a), _p(b), _stream())
+    return x
+
+
+ANCHOR_CHUNK = 1024
+
+
+def anchor_keys_raw(logits, N, h, w, cs, Cc, labels, ignore=255):
+    """logits: fp32 device tensor whose storage from data_ptr() is [N,h,w,cs] (first Cc channels used);
+    labels int64 [N,H,W] -> (key uint8 [N,h*w], hist int32 [N,nchunks,2C])."""
+    if not logits.is_cuda or logits.dtype != _F32 or labels.dtype != torch.int64 or not labels.is_contiguous():
+        raise RuntimeError("anchor_keys: fp32 device logits and contiguous int64 labels required")
+    H, W = labels.shape[1:]
+    nch = -(-(h * w) // ANCHOR_CHUNK)
+    key = torch.empty((N, h * w), device=labels.device, dtype=torch.uint8)
+    hist = torch.empty((N, nch, 2 * Cc), device=labels.device, dtype=torch.int32)
+    _call("dcs_anchor_keys", _p(logits), cs, Cc, _p(labels), N, h, w, H, W, ignore, _p(key), _p(hist),
+          ANCHOR_CHUNK, _stream())
+    return key, hist
+
+
+def anchor_select(key, hist, req, Cc):
+    """req int32 [Q,3] = (image, key, rank) -> flat pixel index int32 [Q]."""
+    N, HW = key.shape
+    Q = req.shape[0]
+    out = torch.empty((Q,), device=key.device, dtype=torch.int32)
+    _call("dcs_anchor_select", _p(key), _p(hist), _p(req), _p(out), Q, N, HW, Cc, ANCHOR_CHUNK, _stream())
+    return out
+
+
+def gather_rows(feat2d, rowidx):
+    A = rowidx.shape[0]
+    Cc = feat2d.shape[-1]
+    X = torch.empty((A, Cc), device=feat2d.device, dtype=_F32)
+    _call("dcs_gather_rows", _p(feat2d), _p(rowidx), _p(X), A, Cc, _stream())
+    return X
+
+
+def scatter_add_rows(gX, rowidx, gfeat):
+    _call("dcs_scatter_add_rows", _p(_req(gX)), _p(rowidx), _p(gfeat), rowidx.shape[0], gX.shape[1], _stream())
+
+
+def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
+    """Contrastive loss on anchors X [A,C] (view-major) with float labels [A].
+
+    mode 0: pixel contrast (utils/loss.py:339-389); 1: SupCon/SimCLR (:175-204).
+    Returns (loss scalar tensor [1], dX [A,C] = d loss / d X)."""
+    _req(X)
+    A, Cc = X.shape
+    ld = -(-A // 32) * 32
+    # S = X X^T on the MFMA GEMM (1x1 conv with the anchors as weights)
+    g = geom_fwd(A, 1, 1, Cc, A, 1, 1, 1, 0, None, ld)
+    S = torch.empty((A, ld), device=X.device, dtype=_F32)
+    _call("dcs_conv_gather", _p(X), _p(X), None, _p(S), C.byref(g), 0, _stream())
+    loss_row = torch.empty((A,), device=X.device, dtype=_F32)
+    G = torch.empty((A, ld), device=X.device, dtype=_F32)
+    _call("dcs_contrast_rows", _p(S), _p(labels), _p(loss_row), _p(G), A, ld, mode, 1.0 / temperature, _stream())
+    loss = torch.empty((1,), device=X.device, dtype=_F32)
+    _call("dcs_sum_scalar", _p(loss_row), _p(loss), A, 1.0 / A, _stream())
+    Gs = torch.empty((A, ld), device=X.device, dtype=_F32)
+    _call("dcs_symmetrize", _p(G), _p(Gs), A, ld, _stream())
+    # dX = (G + G^T) X : GEMM with K = ld (zero padded), weights = X^T [C, ld]
+    Xp = X
+    if ld != A:
+        Xp = torch.zeros((ld, Cc), device=X.device, dtype=_F32)
+        Xp[:A].copy_(X)
+    Xt = transpose(Xp)                                   # [C, ld]
+    g2 = geom_fwd(A, 1, 1, ld, Cc, 1, 1, 1, 0)
+    dX = torch.empty((A, Cc), device=X.device, dtype=_F32)
+    _call("dcs_conv_gather", _p(Gs), _p(Xt), None, _p(dX), C.byref(g2), 0, _stream())
+    return loss, dX
+
+
+def sum_scalar(x, scale=1.0):
+    out = torch.empty((1,), device=x.device, dtype=_F32)
+    _call("dcs_sum_scalar", _p(_req(x)), _p(out), x.numel(), float(scale), _stream())
+    return out
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, step):
+    _call("dcs_adam_step", _p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, wd, step, _stream())
+
+
+def axpy(y, x, a):
+    _call("dcs_axpy", _p(y), _p(x), x.numel(), float(a), _stream())
+
+
+def add_rowvec_bcast(g, v, scale):
+    N, H, W, Cc = g.shape
+    _call("dcs_add_rowvec_bcast", _p(g), _p(_req(v)), N, H * W, Cc, float(scale), _stream())
+
+
+def relu_bwd(g, z):
+    out = torch.empty_like(g)
+    _call("dcs_relu_bwd_rows", _p(_req(g)), _p(_req(z)), _p(out), g.numel(), _stream())
+    return out

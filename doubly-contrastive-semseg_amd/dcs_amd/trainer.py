@@ -1,0 +1,149 @@
+"""Train-step harness: the body of the reference's ``Trainer.train`` loop
+(trainer.py:62-215) and the pieces of ``InitOpts`` it relies on
+(utils/init_trainer.py:97-113 model, :163-177 ADAM groups, :215-223 criteria).
+
+``TrainStep.step(sample)`` takes what ``dataloaders/`` would deliver (dicts with
+'left', 'label', 'weather', 'label_distance_weight'; a pair of dicts for the
+``supcon*`` criteria) and performs forward, the criterion switch, backward and
+the optimizer step on one MI355X.
+"""
+from __future__ import annotations
+
+import types
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .losses import (BoundaryAwareFocalLoss, FocalLoss2, PixelContrastLoss, SemsegCrossEntropy, SupConLoss)
+from .model import WeatherClassifier, WeatherNet
+
+CRITERIA = ("supcon_focal", "supcon_simclr_focal", "pixelcontrast_focal", "supcon_pixelcontrast_focal",
+            "supcon_simclr_pixelcontrast_focal", "crossentropy", "supcon_crossentropy",
+            "supcon_simclr_cross_entropy", "focal", "plain_focal", "none")
+
+
+def make_opts(**kw):
+    """The subset of options.py the hot path reads, with the reference's defaults."""
+    d = dict(model="resnet18", deeplab=False, criterion="supcon_pixelcontrast_focal", batch_size=8, lr=4e-4,
+             weight_decay=1e-4, optimizer_policy="ADAM", dataset="acdc", weather_num=4, num_classes=19,
+             train_semantic=True, with_depth_level_loss=False, no_class_weights=False, no_EDT=False,
+             epochs=400, last_lr=1e-6)
+    d.update(kw)
+    return types.SimpleNamespace(**d)
+
+
+class DcsAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (L2 weight decay folded into the gradient) on the fused HIP kernel."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        for group in self.param_groups:
+            b1, b2 = group["betas"]
+            for p in group["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["step"] = 0
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+                g = p.grad
+                if g.stride() != p.stride():
+                    g = g.contiguous(memory_format=torch.channels_last) if p.dim() == 4 else g.contiguous()
+                ops.adam_step(p, g, st["exp_avg"], st["exp_avg_sq"], float(group["lr"]), b1, b2, group["eps"],
+                              float(group["weight_decay"]), st["step"])
+
+
+class TrainStep:
+    def __init__(self, opts, class_weight: Optional[torch.Tensor] = None, device="cuda"):
+        self.opts = opts
+        self.device = torch.device(device)
+        opts.weight = class_weight
+        self.model = WeatherNet(opts, num_classes=opts.num_classes, device=self.device, backbone=opts.model,
+                                train_semantic=opts.train_semantic).to(self.device)
+        self.weather_clf = WeatherClassifier(opts, weather_class_num=opts.weather_num).to(self.device)
+        w = class_weight
+        self.criterion = BoundaryAwareFocalLoss(gamma=0.5, num_classes=opts.num_classes, ignore_id=255, weight=w,
+                                                device=self.device, opts=opts)
+        self.focal_criterion = FocalLoss2(gamma=.5, num_classes=opts.num_classes, ignore_id=255, weight=w,
+                                          device=self.device)
+        self.supcon_criterion = SupConLoss(temperature=0.07, contrast_mode="all", base_temperature=0.07, weight=w,
+                                           device=self.device, opts=opts)
+        self.pixelcontrast_criterion = PixelContrastLoss(device=self.device)
+        self.ce_criterion = SemsegCrossEntropy(num_classes=opts.num_classes, ignore_id=255)
+        fine_tune_factor = 4                                       # utils/init_trainer.py:169-177
+        self.optimizer = DcsAdam([
+            {"params": list(self.model.random_init_params()), "lr": opts.lr, "weight_decay": opts.weight_decay},
+            {"params": list(self.model.fine_tune_params()), "lr": opts.lr / fine_tune_factor,
+             "weight_decay": opts.weight_decay / fine_tune_factor}], betas=(0.9, 0.99))
+        self.num_iter = 0
+        self.model.train()
+
+    def step(self, sample, do_optimizer_step=True) -> Dict[str, torch.Tensor]:
+        o = self.opts
+        crit = o.criterion
+        if "supcon" in crit:                                       # trainer.py:66-72
+            sample0, sample1 = sample
+            sample = dict(sample0)
+            sample["left"] = torch.cat([sample0["left"], sample1["left"]], dim=0)
+        self.num_iter += 1
+        dev = self.device
+        left = sample["left"].to(dev, dtype=getattr(o, "dtype", torch.float32))
+        labels = sample["label"].to(dev, dtype=torch.long)
+        gt_weather = sample["weather"].to(dev) if "weather" in sample else None
+        supcon_flag = "supcon" in crit
+        left_seg, left_seg_beforeup, fine_feat, fine_feat0 = self.model(left, return_supcon_feature=supcon_flag)
+        zero = torch.zeros(1, device=dev)
+        out = dict(supcon=zero, simclr=zero, pixel=zero, seg=zero, ce=zero)
+        if o.dataset == "acdc" and gt_weather is not None:        # trainer.py:109-114 (logged only)
+            out["pred_weather"] = self.weather_clf(fine_feat0)
+        if crit == "supcon_focal":
+            out["supcon"] = self.supcon_criterion(fine_feat, class_labels=gt_weather, mask=None)
+            out["seg"] = self.criterion(left_seg, labels, sample)
+            total = out["supcon"] * 1 / o.batch_size + out["seg"] * 1.2
+        elif crit == "supcon_simclr_focal":
+            out["simclr"] = self.supcon_criterion(fine_feat, class_labels=None, mask=None)
+            out["seg"] = self.criterion(left_seg, labels, sample)
+            total = out["simclr"] * 1 / o.batch_size + out["seg"] * 1.2
+        elif crit == "pixelcontrast_focal":
+            out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
+            out["seg"] = self.criterion(left_seg, labels, sample)
+            total = out["pixel"] * 1 / o.batch_size + out["seg"] * 1.2
+        elif crit == "supcon_pixelcontrast_focal":
+            out["supcon"] = self.supcon_criterion(fine_feat, class_labels=gt_weather, mask=None)
+            out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
+            out["seg"] = self.criterion(left_seg, labels, sample)
+            total = 1 / o.batch_size * (out["supcon"] + out["pixel"]) + out["seg"] * 1.2
+        elif crit == "supcon_simclr_pixelcontrast_focal":
+            out["simclr"] = self.supcon_criterion(fine_feat, class_labels=None, mask=None)
+            out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
+            out["seg"] = self.criterion(left_seg, labels, sample)
+            total = 1 / o.batch_size * (out["simclr"] + out["pixel"]) + out["seg"] * 1.2
+        elif crit == "crossentropy":
+            out["ce"] = self.ce_criterion(left_seg, labels)
+            total = out["ce"]
+        elif crit == "supcon_crossentropy":
+            out["supcon"] = self.supcon_criterion(fine_feat, class_labels=gt_weather, mask=None)
+            out["ce"] = self.ce_criterion(left_seg, labels)
+            total = out["ce"] + out["supcon"]
+        elif crit == "supcon_simclr_cross_entropy":                 # trainer.py:193-198 adds the zero supcon_loss
+            out["simclr"] = self.supcon_criterion(fine_feat, class_labels=None, mask=None)
+            out["ce"] = self.ce_criterion(left_seg, labels)
+            total = out["ce"] + out["supcon"]
+        else:
+            out["seg"] = self.criterion(left_seg, labels, sample)
+            total = out["seg"]
+        self.optimizer.zero_grad()
+        self.supcon_criterion.zero_grad()
+        total.backward()
+        if do_optimizer_step:
+            self.optimizer.step()
+        out.update(total=total.detach(), left_seg=left_seg, left_seg_beforeup=left_seg_beforeup,
+                   fine_feat=fine_feat, labels=labels)
+        return out

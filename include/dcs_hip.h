@@ -1,0 +1,194 @@
+/*
+ * dcs_hip.h -- C ABI of libdcs_hip.so: the MI355X (gfx950) kernels behind the
+ * doubly-contrastive segmentation train step.
+ *
+ * Boundary rules:
+ *   - plain C: raw DEVICE pointers, explicit shapes, a hipStream_t passed as void*;
+ *   - no allocation inside: every workspace is a caller-provided pointer;
+ *   - launch-only: never synchronises, never throws; returns 0 or a negative DCS_E_* code;
+ *   - thread-safe as long as streams and buffers differ.
+ * Activations are NHWC fp32 ("pixel rows of C contiguous channels").  Convolution weights are
+ * KRSC fp32 = the physical layout of a PyTorch OIHW tensor in channels_last memory format, so
+ * the reference's state_dict shapes are kept while the kernels read K-contiguous rows.
+ *
+ * Each entry point cites the reference code it replaces (paths relative to the reference root).
+ */
+#ifndef DCS_HIP_H
+#define DCS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCS_OK 0
+#define DCS_E_ARG (-1)      /* bad shape / alignment / null pointer */
+#define DCS_E_LAUNCH (-2)   /* hipGetLastError() != hipSuccess after the launch */
+#define DCS_E_UNSUPPORTED (-3)
+
+#define DCS_MAX_TAPS 49
+
+/* Gather geometry shared by forward conv, data-gradient and weight-gradient kernels.
+ * The GEMM row index m enumerates a sub-grid (n, ty, tx), ty < TY, tx < TX of the DESTINATION
+ * tensor: dest pixel = (ty*dsy + dy0, tx*dsx + dx0).  For tap t the SOURCE pixel is
+ * (ty*sy + offy[t], tx*sx + offx[t]) (zero outside [0,SH)x[0,SW)); its K channels are multiplied
+ * with weight row segment  w[co*wstride + wofs[t] .. +K).
+ *   forward conv  : sub-grid = whole output, sy = stride, off = r - pad, wofs = (r*S+s)*Cin
+ *   data gradient : one launch per input parity class, sy = 1, off = (py+pad-r)/stride
+ *   stem (7x7/2 on NHWC4): tap = kernel row r, the 7 kernel columns x 4 channels form one 32-wide
+ *                   K chunk (28 valid), mode flag stem = 1.                                      */
+typedef struct DcsConvGeom {
+  int32_t N, SH, SW;          /* source tensor [N,SH,SW,*]                      */
+  int32_t DH, DW;             /* destination tensor [N,DH,DW,*]                 */
+  int32_t TY, TX;             /* sub-grid extent; M = N*TY*TX                   */
+  int32_t sy, sx;             /* source step per sub-grid index                 */
+  int32_t dsy, dsx, dy0, dx0; /* destination step / origin                      */
+  int32_t K;                  /* channels per tap taken from the source         */
+  int32_t Cout;               /* GEMM N                                         */
+  int32_t ntaps;
+  int32_t wstride;            /* floats between consecutive weight rows         */
+  int32_t src_cstride;        /* floats between consecutive source pixels       */
+  int32_t dst_cstride;        /* floats between consecutive destination pixels  */
+  int32_t stem;               /* 1: NHWC4 stem mode (see above)                 */
+  int16_t offy[DCS_MAX_TAPS];
+  int16_t offx[DCS_MAX_TAPS];
+  int32_t wofs[DCS_MAX_TAPS];
+} DcsConvGeom;
+
+/* ---- convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------------
+ * replaces nn.Conv2d forward (network/backbone/resnet_pyramid.py:23-25,:139,:110-112;
+ * network/utils.py:46-47) and the data half of aten::convolution_backward.
+ * dst[m, co] (+)= bias[co] + sum_t sum_k src[gather(m,t), k] * wgt[co, wofs[t]+k]              */
+int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
+                    const DcsConvGeom* geom, int accumulate, void* stream);
+
+/* Weight gradient, split over pixel ranges.  slab[split][co][wstride] receives partial sums for
+ * split = split0 .. split0+nsplit-1 (every element of those slab slices is written).
+ * replaces the weight half of aten::convolution_backward.                                      */
+int dcs_conv_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom,
+                   int dy_cstride, int split0, int nsplit, void* stream);
+
+/* dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], fixed order (deterministic). */
+int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, void* stream);
+
+/* [Cout][R][S][Cin] -> [Cin][R][S][Cout] (weights for the data-gradient GEMM). */
+int dcs_pack_dgrad_weight(const float* w_krsc, float* w_crsk, int Cout, int R, int S, int Cin, void* stream);
+/* stem: [64][7][7][3] <-> [64][7][8][4] zero padded (dir 0: pack, 1: unpack). */
+int dcs_pack_stem_weight(const float* in, float* out, int Cout, int dir, void* stream);
+/* out[c][r] = in[r][c]  (in: [R][C]) */
+int dcs_transpose(const float* in, float* out, int R, int C, void* stream);
+
+/* ---- per-channel reductions and BatchNorm ----------------------------------------------------
+ * replaces nn.BatchNorm2d train/eval forward+backward (resnet_pyramid.py:61,:65,:159-161;
+ * network/utils.py:36-41).                                                                     */
+/* partial[b][g][2][C]: per group g of rows, sum and sum of squares of x[b][rows][C].
+ * mode 0: (sum x, sum x^2).  mode 1: BN backward sums (sum gm, sum gm*xhat) where
+ * gm = g * mask, mask = (masksrc ? masksrc > 0 : (relu ? y*scale+shift > 0 : 1)),
+ * xhat = (y - mean) * invstd.  bn = [scale, shift, mean, invstd] x C (may be null in mode 0).  */
+int dcs_colsum_partial(const float* x, const float* y, const float* masksrc, const float* bn,
+                       float* partial, int B, int64_t rows, int C, int cstride, int groups,
+                       int mode, int relu, void* stream);
+/* out[b][2][C] = sum over groups, accumulated in double, times scale. */
+int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale, void* stream);
+/* From sums[2][C] over `count` rows: bn[0..4C) = scale, shift, mean, invstd; updates running
+ * mean/var `repeats` times (momentum, unbiased variance) when running_mean != null.
+ * training = 0: ignores sums and derives scale/shift from the running statistics.            */
+int dcs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float* bn, int C, double count, float eps, float momentum,
+                    int repeats, int training, void* stream);
+/* Re-applies the running-stat EMA with saved batch statistics (activation-checkpoint recompute
+ * side effect): bn holds mean/invstd; count rows. */
+int dcs_bn_ema_again(const float* bn, float* running_mean, float* running_var, int C, double count,
+                     float eps, float momentum, void* stream);
+
+/* z = act(y*scale+shift [+ r | + r*scale2+shift2]); act = relu if relu.  bn2 null -> identity r. */
+int dcs_bn_act(const float* y, const float* bn, const float* r, const float* bn2, float* z,
+               int64_t rows, int C, int relu, void* stream);
+/* BN backward apply: gm = g*mask; dy (+)= gamma*invstd*(gm - s0/cnt - xhat*s1/cnt);
+ * optional gm_out (+)= gm.  sums = [2][C] from dcs_colsum_* mode 1.  dgamma/dbeta (+)= s1/s0. */
+int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
+                     const float* gamma, const float* sums, float* dy, float* gm_out,
+                     float* dgamma, float* dbeta, int64_t rows, int C, int relu, int acc_dy,
+                     int acc_gm, int acc_param, void* stream);
+
+/* ---- pyramid / pooling / resize -------------------------------------------------------------*/
+/* resnet_pyramid.py:296-314: (x-mean)/std then bicubic 1/2 and 1/4 (A=-0.75, no antialias).
+ * img NCHW [N,3,H,W] raw; out0/1/2 NHWC4 (4th channel 0) at H, H/2, H/4 (floor). */
+int dcs_normalize_pyramid(const float* img, float* out0, float* out1, float* out2, int N, int H, int W,
+                          const float* mean3, const float* std3, void* stream);
+/* resnet_pyramid.py:322-325: maxpool3x3/2 pad1 of relu(y*scale+shift).  idx: uint8 argmax 0..8. */
+int dcs_bn_relu_maxpool(const float* y, const float* bn, float* out, uint8_t* idx, int N, int H, int W,
+                        int C, void* stream);
+/* gz[n,iy,ix,c] = sum of g[outputs whose argmax is (iy,ix)]  (dense, y resolution). */
+int dcs_maxpool_bwd(const float* g, const uint8_t* idx, float* gz, int N, int H, int W, int C, void* stream);
+/* network/utils.py:92-102: t = bilinear(x -> [OH,OW], align_corners=False) + ((s0+s1)+s2). */
+int dcs_upsample_add(const float* x, const float* s0, const float* s1, const float* s2, float* t,
+                     int N, int IH, int IW, int OH, int OW, int C, void* stream);
+/* adjoint of the bilinear part: gx[n,iy,ix,c] (+)= sum_o w(o,i) g[n,oy,ox,c]. */
+int dcs_upsample_bwd(const float* g, float* gx, int N, int IH, int IW, int OH, int OW, int C,
+                     int accumulate, void* stream);
+/* network/utils.py:8 on the logits: x NHWC [N,IH,IW,cs] (first C channels) -> out NCHW [N,C,OH,OW]. */
+int dcs_upsample_to_nchw(const float* x, float* out, int N, int IH, int IW, int cs, int C, int OH, int OW,
+                         void* stream);
+/* adjoint: g NCHW [N,C,OH,OW] * gscale -> gx NHWC [N,IH,IW,cs] (channels >= C zeroed). */
+int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, float* gx, int N, int IH, int IW, int cs,
+                             int C, int OH, int OW, void* stream);
+
+/* ---- segmentation losses (utils/loss.py:39-80; nn.CrossEntropyLoss) --------------------------
+ * logits NCHW [N,C,H,W]; target int64 [N,H,W]; ldw [N,H,W]; cw [C].
+ * mode 0: boundary-aware focal (w*alpha), 1: plain_focal, 2: no_class_weights, 3: no_EDT,
+ *      4: cross entropy with ignore_index (mean over non-ignored).
+ * Focal modes rewrite target==ignore -> 0 in place (loss.py:43).  grad receives the UNSCALED
+ * d(sum)/d(logit); partial[blocks][2] = (sum loss, count).  out[0]=loss, out[1]=count after
+ * dcs_seg_loss_final, which also leaves 1/count (or 0) in out[2] for the backward scale.      */
+int dcs_seg_loss(const float* logits, int64_t* target, const float* ldw, const float* cw, float* grad,
+                 float* partial, int N, int C, int H, int W, int mode, float gamma, int ignore,
+                 int blocks, void* stream);
+int dcs_seg_loss_final(const float* partial, float* out, int blocks, void* stream);
+/* x[i] *= a[0]*b[0] (device scalars; b may be null). */
+int dcs_scale_inplace(float* x, int64_t n, const float* a, const float* b, void* stream);
+
+/* ---- hard-anchor sampling (utils/loss.py:264-337, :396-410) ----------------------------------*/
+/* pred[n,p] = argmax_c logits[n,p,c] (first max), lab[n,p] = labels[n, floor(y*H/h), floor(x*W/w)];
+ * key[n,p] = 255 if lab is ignore or out of [0,C), else lab*2 + (pred==lab ? 1 : 0).
+ * hist[n][chunk][2C] counts keys per chunk of `chunk` pixels (chunk % 256 == 0).            */
+int dcs_anchor_keys(const float* logits, int cs, int C, const int64_t* labels, int N, int h, int w,
+                    int H, int W, int ignore, uint8_t* key, int32_t* hist, int chunk, void* stream);
+/* req[q] = {n, key, rank}; out[q] = flat pixel index of the rank-th pixel with that key in image n
+ * (ascending index order = nonzero() order); -1 if absent.  hist as produced above. */
+int dcs_anchor_select(const uint8_t* key, const int32_t* hist, const int32_t* req, int32_t* out, int Q,
+                      int N, int HW, int C, int chunk, void* stream);
+/* X[a][0..C) = feat[(img[a]*HW + pix[a]) * C ..]  and the adjoint gfeat[...] += gX[a]. */
+int dcs_gather_rows(const float* feat, const int32_t* rowidx, float* X, int A, int C, void* stream);
+int dcs_scatter_add_rows(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, void* stream);
+
+/* ---- contrastive rows (utils/loss.py:175-204 and :361-386) -----------------------------------
+ * S [A,ld] = C C^T (from dcs_conv_gather in 1x1 mode), scaled by inv_temp = 1/T on read.  For every row i < A:
+ *   max-subtract, L2-normalise, masked exp/log reductions; loss_row[i]; G[i][j] = d(mean loss)/dS_ij
+ * (w.r.t. the unscaled S, already divided by the number of rows A).  labels: float [A].  mode 0: pixel contrast
+ * (denominator exp(L_ij)+neg_i), mode 1: SupCon/SimCLR (denominator sum_{k!=i}).  `selfmask` as the
+ * reference: positives exclude j == i.  Rows with no positives give NaN like the reference.     */
+int dcs_contrast_rows(const float* S, const float* labels, float* loss_row, float* G, int A, int ld,
+                      int mode, float inv_temp, void* stream);
+/* Gs[i][j] = G[i][j] + G[j][i]  (A x ld, zero padded to ld). */
+int dcs_symmetrize(const float* G, float* Gs, int A, int ld, void* stream);
+/* out[0] = scale * sum x[0..n) in double (single block, deterministic). */
+int dcs_sum_scalar(const float* x, float* out, int n, float scale, void* stream);
+
+/* ---- optimizer (torch.optim.Adam semantics, utils/init_trainer.py:169-177) ------------------*/
+int dcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float wd, int step, void* stream);
+
+/* elementwise helpers */
+int dcs_axpy(float* y, const float* x, int64_t n, float a, void* stream);           /* y += a*x */
+int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW, int C, float scale,
+                         void* stream);                                           /* g[n,p,c] += scale*v[n,c] */
+int dcs_relu_bwd_rows(const float* g, const float* z, float* out, int64_t n, void* stream); /* out = g*(z>0) */
+
+const char* dcs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCS_HIP_H */

@@ -1,0 +1,363 @@
+"""TEST INFRASTRUCTURE: a torch-CPU emulation of every function in ``dcs_amd.ops``.
+
+It lets the CPU test-suite (``-m "not gpu"``) exercise the HOST logic of the
+product -- the hand-written forward/backward graph wiring in ``dcs_amd.model``,
+the autograd Functions and sampler planning in ``dcs_amd.losses``, the train
+step and the data-parallel exchange -- without a GPU.  Each function states the
+CONTRACT of the corresponding C-ABI kernel (include/dcs_hip.h) in plain torch
+ops; the GPU tests check the real kernels against the same contracts.
+It is never imported by the product; ``install()`` monkeypatches ``dcs_amd.ops``
+inside a test process only.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def _nchw(x):
+    return x.permute(0, 3, 1, 2)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def require_device(t, what="input"):
+    return None
+
+
+def krsc(w):
+    return w.permute(0, 2, 3, 1)
+
+
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None):
+    y = _nhwc(F.conv2d(_nchw(x), w, bias, stride, pad))
+    if dst_cs and dst_cs != y.shape[-1]:
+        y = F.pad(y, (0, dst_cs - y.shape[-1]))
+    return y.contiguous()
+
+
+def pack_dgrad_weight(w):
+    return w.permute(1, 2, 3, 0).contiguous()          # [Cin,R,S,Cout]
+
+
+def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None):
+    Cin, R, S, Cout = wp.shape
+    w = wp.permute(3, 0, 1, 2)[:, :, :, :]              # [Cout,Cin,R,S]
+    N = dy.shape[0]
+    g = torch.nn.grad.conv2d_input((N, Cin, in_hw[0], in_hw[1]), w.contiguous(), _nchw(dy[..., :Cout]).contiguous(),
+                                   stride, pad)
+    g = _nhwc(g)
+    if out is None:
+        return g
+    if accumulate:
+        out.add_(g)
+    else:
+        out.copy_(g)
+    return out
+
+
+def conv_wgrad(x, dy, dw, stride, pad, accumulate):
+    Cout = dw.shape[0]
+    g = torch.nn.grad.conv2d_weight(_nchw(x).contiguous(), dw.shape, _nchw(dy[..., :Cout]).contiguous(), stride, pad)
+    if accumulate:
+        dw.add_(g)
+    else:
+        dw.copy_(g)
+
+
+def pack_stem_weight(w):
+    return F.pad(w.permute(0, 2, 3, 1), (0, 1, 0, 1)).contiguous()   # [64,7,8,4]
+
+
+def unpack_stem_weight(wp, like):
+    o = torch.empty_like(like)
+    o.copy_(wp[:, :, :7, :3].permute(0, 3, 1, 2))
+    return o
+
+
+def _stem_w(wp):
+    return wp[:, :, :7, :3].permute(0, 3, 1, 2).contiguous()
+
+
+def stem_conv(p, wp):
+    return _nhwc(F.conv2d(_nchw(p[..., :3]), _stem_w(wp), None, 2, 3))
+
+
+def stem_wgrad(p, dy, dwp, accumulate):
+    g = torch.nn.grad.conv2d_weight(_nchw(p[..., :3]).contiguous(), (64, 3, 7, 7), _nchw(dy).contiguous(), 2, 3)
+    gp = F.pad(g.permute(0, 2, 3, 1), (0, 1, 0, 1))
+    if accumulate:
+        dwp.add_(gp)
+    else:
+        dwp.copy_(gp)
+
+
+def linear(x, w, bias=None):
+    return F.linear(x, w, bias)
+
+
+def transpose(x):
+    return x.t().contiguous()
+
+
+def linear_wgrad(x, dy, dw, accumulate=False):
+    g = dy.t() @ x
+    if accumulate:
+        dw.add_(g)
+    else:
+        dw.copy_(g)
+
+
+def colsum(x2d, B=1, scale=1.0):
+    total, C = x2d.shape
+    v = x2d.reshape(B, total // B, C).double()
+    return (torch.stack([v.sum(1), (v * v).sum(1)], dim=1) * scale).to(x2d.dtype)
+
+
+def bn_finalize(sums, gamma, beta, rm, rv, count, training, repeats=1, eps=1e-5, momentum=0.1, update=True):
+    if training:
+        mean = sums[0, 0].double() / count
+        var = (sums[0, 1].double() / count - mean * mean).clamp_min(0)
+        invstd = 1.0 / torch.sqrt(var + eps)
+        if update:
+            vu = (var * (count / max(count - 1, 1))).to(rm.dtype)
+            for _ in range(repeats):
+                rm.mul_(1 - momentum).add_(mean.to(rm.dtype), alpha=momentum)
+                rv.mul_(1 - momentum).add_(vu, alpha=momentum)
+        mean, invstd = mean.to(gamma.dtype), invstd.to(gamma.dtype)
+    else:
+        mean = rm.clone()
+        invstd = 1.0 / torch.sqrt(rv + eps)
+    sc = gamma.detach() * invstd
+    return torch.stack([sc, beta.detach() - mean * sc, mean, invstd]).contiguous()
+
+
+def bn_ema_again(bn, rm, rv, count, eps=1e-5, momentum=0.1):
+    mean, invstd = bn[2], bn[3].double()
+    var = (1.0 / (invstd * invstd) - eps).clamp_min(0)
+    vu = (var * (count / max(count - 1, 1))).to(rm.dtype)
+    rm.mul_(1 - momentum).add_(mean, alpha=momentum)
+    rv.mul_(1 - momentum).add_(vu, alpha=momentum)
+
+
+def bn_act(y, bn, r=None, bn2=None, relu=True):
+    o = y * bn[0] + bn[1]
+    if r is not None:
+        o = o + (r * bn2[0] + bn2[1] if bn2 is not None else r)
+    return F.relu(o) if relu else o
+
+
+def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=False, dy_out=None, acc_dy=False,
+           dgamma=None, dbeta=None, acc_param=False):
+    C = y.shape[-1]
+    rows = y.numel() // C
+    gm = g
+    if masksrc is not None:
+        gm = g * (masksrc > 0)
+    elif relu:
+        gm = g * ((y * bn[0] + bn[1]) > 0)
+    xhat = (y - bn[2]) * bn[3]
+    s0 = gm.reshape(-1, C).double().sum(0).to(y.dtype)
+    s1 = (gm * xhat).reshape(-1, C).double().sum(0).to(y.dtype)
+    if dgamma is not None:
+        if acc_param:
+            dgamma.add_(s1); dbeta.add_(s0)
+        else:
+            dgamma.copy_(s1); dbeta.copy_(s0)
+    dy = None
+    if want_dy:
+        v = gamma.detach() * bn[3] * (gm - s0 / rows - xhat * (s1 / rows))
+        if dy_out is not None:
+            if acc_dy:
+                dy_out.add_(v)
+            else:
+                dy_out.copy_(v)
+            dy = dy_out
+        else:
+            dy = v.contiguous()
+    return dy, (gm.contiguous() if want_gm else None)
+
+
+def normalize_pyramid(img, mean3, std3):
+    x0 = (img - mean3.view(1, 3, 1, 1)) / std3.view(1, 3, 1, 1)
+    outs = [x0] + [F.interpolate(x0, scale_factor=1 / 2 ** l, mode="bicubic", align_corners=None) for l in (1, 2)]
+    return tuple(F.pad(_nhwc(o), (0, 1)).contiguous() for o in outs)
+
+
+def bn_relu_maxpool(y, bn):
+    z = F.relu(y * bn[0] + bn[1])
+    out, idx = F.max_pool2d(_nchw(z), 3, 2, 1, return_indices=True)
+    return _nhwc(out), _nhwc(idx)                       # idx: flat input index (emulation-private encoding)
+
+
+def maxpool_bwd(g, idx, H, W):
+    N, OH, OW, C = g.shape
+    gz = torch.zeros((N, C, H * W), dtype=g.dtype)
+    gz.scatter_add_(2, _nchw(idx).reshape(N, C, -1), _nchw(g).reshape(N, C, -1))
+    return _nhwc(gz.reshape(N, C, H, W))
+
+
+def upsample_add(x, skips, OH, OW):
+    t = F.interpolate(_nchw(x), (OH, OW), mode="bilinear", align_corners=False)
+    sk = 0
+    for s in skips:
+        sk = sk + _nchw(s)
+    return _nhwc(t + sk)
+
+
+@torch.enable_grad()
+def upsample_bwd(g, IH, IW, out=None, accumulate=False):
+    N, OH, OW, C = g.shape
+    x = torch.zeros((N, C, IH, IW), requires_grad=True, dtype=g.dtype)
+    y = F.interpolate(x, (OH, OW), mode="bilinear", align_corners=False)
+    (gx,) = torch.autograd.grad(y, x, _nchw(g))
+    gx = _nhwc(gx)
+    if out is None:
+        return gx
+    if accumulate:
+        out.add_(gx)
+    else:
+        out.copy_(gx)
+    return out
+
+
+def upsample_to_nchw(x, C, OH, OW):
+    return F.interpolate(_nchw(x[..., :C]), (OH, OW), mode="bilinear", align_corners=False).contiguous()
+
+
+@torch.enable_grad()
+def upsample_to_nchw_bwd(g, IH, IW, cs, gscale=None):
+    N, C, OH, OW = g.shape
+    x = torch.zeros((N, C, IH, IW), requires_grad=True, dtype=g.dtype)
+    y = F.interpolate(x, (OH, OW), mode="bilinear", align_corners=False)
+    (gx,) = torch.autograd.grad(y, x, g * (gscale[0] if gscale is not None else 1.0))
+    return F.pad(_nhwc(gx), (0, cs - C)).contiguous()
+
+
+@torch.enable_grad()
+def seg_loss(logits, target, ldw, cw, mode, gamma=0.5, ignore=255):
+    N, C, H, W = logits.shape
+    x = logits.detach().permute(0, 2, 3, 1).reshape(-1, C).clone().requires_grad_(True)
+    if mode == "ce":
+        t = target.reshape(-1)
+        valid = t != ignore
+        tt = torch.where(valid, t, torch.zeros_like(t))
+        logpt = F.log_softmax(x, -1).gather(1, tt.view(-1, 1)).view(-1)
+        s = -(logpt * valid).sum()
+        cnt = valid.sum().to(x.dtype)
+    else:
+        target[target == ignore] = 0
+        t = target.reshape(-1)
+        a = ldw.reshape(-1)
+        w = cw[t] if cw is not None else torch.ones_like(a)
+        logpt = F.log_softmax(x, -1).gather(1, t.view(-1, 1)).view(-1)
+        mod = torch.exp(gamma * (1 - logpt.detach().exp()))
+        coef = {"full": w * a * mod, "plain_focal": mod, "no_class_weights": a * mod, "no_EDT": w * mod}[mode]
+        s = -(coef * logpt).sum()
+        cnt = (a > 0).sum().to(x.dtype)
+    (g,) = torch.autograd.grad(s, x)
+    grad = g.reshape(N, H, W, C).permute(0, 3, 1, 2).contiguous()
+    z = torch.zeros((), dtype=x.dtype)
+    out = torch.stack([s.detach() / cnt if cnt > 0 else z, cnt, 1.0 / cnt if cnt > 0 else z])
+    return out, grad
+
+
+def scale_inplace(x, a, b=None):
+    x.mul_(a[0] * (b[0] if b is not None else 1.0))
+    return x
+
+
+ANCHOR_CHUNK = 1024
+
+
+def anchor_keys_raw(logits, N, h, w, cs, Cc, labels, ignore=255):
+    lg = torch.as_strided(logits, (N, h, w, Cc), (h * w * cs, w * cs, cs, 1))
+    pred = lg.argmax(-1).reshape(N, -1)
+    lab = F.interpolate(labels.unsqueeze(1).float(), (h, w), mode="nearest").squeeze(1).long().reshape(N, -1)
+    ok = (lab != ignore) & (lab >= 0) & (lab < Cc)
+    key = torch.where(ok, lab * 2 + (pred == lab).long(), torch.full_like(lab, 255)).to(torch.uint8)
+    nch = -(-(h * w) // ANCHOR_CHUNK)
+    hist = torch.zeros((N, nch, 2 * Cc), dtype=torch.int32)
+    for n in range(N):
+        for ck in range(nch):
+            seg = key[n, ck * ANCHOR_CHUNK:(ck + 1) * ANCHOR_CHUNK].long()
+            seg = seg[seg != 255]
+            hist[n, ck] = torch.bincount(seg, minlength=2 * Cc)[:2 * Cc].int()
+    return key, hist
+
+
+def anchor_select(key, hist, req, Cc):
+    out = torch.empty((req.shape[0],), dtype=torch.int32)
+    for q, (n, k, r) in enumerate(req.tolist()):
+        idx = (key[n] == k).nonzero().reshape(-1)
+        out[q] = int(idx[r]) if r < idx.numel() else -1
+    return out
+
+
+def gather_rows(feat2d, rowidx):
+    return feat2d[rowidx.long()].contiguous()
+
+
+def scatter_add_rows(gX, rowidx, gfeat):
+    C = gX.shape[1]
+    gfeat.view(-1, C).index_add_(0, rowidx.long(), gX)
+
+
+@torch.enable_grad()
+def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
+    x = X.detach().clone().requires_grad_(True)
+    A = x.shape[0]
+    s = (x @ x.t()) / temperature
+    s = s - s.max(1, keepdim=True)[0].detach()
+    L = F.normalize(s)
+    same = (labels.view(-1, 1) == labels.view(1, -1)).to(x.dtype)
+    off = 1.0 - torch.eye(A, dtype=x.dtype)
+    pos = same * off
+    if mode == 0:
+        neg = (torch.exp(L) * (1 - same)).sum(1, keepdim=True)
+        lp = L - torch.log(torch.exp(L) + neg)
+    else:
+        lp = L - torch.log((torch.exp(L) * off).sum(1, keepdim=True))
+    loss = (-(pos * lp).sum(1) / pos.sum(1)).mean()
+    (dX,) = torch.autograd.grad(loss, x)
+    return loss.detach().reshape(1), dX.contiguous()
+
+
+def sum_scalar(x, scale=1.0):
+    return (x.double().sum() * scale).to(x.dtype).reshape(1)
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, wd, step):
+    with torch.no_grad():
+        gr = g + wd * p
+        m.mul_(beta1).add_(gr, alpha=1 - beta1)
+        v.mul_(beta2).addcmul_(gr, gr, value=1 - beta2)
+        bc1, bc2 = 1 - beta1 ** step, 1 - beta2 ** step
+        p.addcdiv_(m, v.sqrt() / math.sqrt(bc2) + eps, value=-lr / bc1)
+
+
+def axpy(y, x, a):
+    y.add_(x, alpha=a)
+
+
+def add_rowvec_bcast(g, v, scale):
+    g.add_(v.view(v.shape[0], 1, 1, -1) * scale)
+
+
+def relu_bwd(g, z):
+    return g * (z > 0)
+
+
+def install(monkeypatch):
+    """Replace every public function of dcs_amd.ops by its emulation (test process only)."""
+    import dcs_amd.ops as real
+    me = globals()
+    for name in dir(real):
+        if name.startswith("_") or name not in me or not callable(me[name]):
+            continue
+        monkeypatch.setattr(real, name, me[name])
+    missing = [n for n in ("conv_fwd", "conv_dgrad", "conv_wgrad", "bn_bwd", "seg_loss", "contrast_fwd_bwd")
+               if getattr(real, n) is not me[n]]
+    assert not missing, missing

@@ -1,0 +1,337 @@
+"""GPU: every kernel of libdcs_hip.so, called through the C ABI (dcs_amd.ops -> ctypes), against the torch-CPU
+statement of its contract (tests/emu_ops.py) on seeded inputs, including odd extents, ragged tiles
+(M, Cout, K not multiples of the tile sizes), stride-2 parity classes and accumulate modes.
+Tolerances: fp32 kernels vs fp32/fp64 CPU math -> 2e-5 relative to the tensor's max (written per test)."""
+import numpy as np
+import pytest
+import torch
+
+import emu_ops as E
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import dcs_amd.ops as real
+    real._lib.load()
+    return real
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = np.random.default_rng(seed)
+    return torch.from_numpy((g.standard_normal(shape) * scale).astype(np.float32))
+
+
+def cl(w):
+    return w.contiguous(memory_format=torch.channels_last)
+
+
+def close(a, b, tol=2e-5, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(float(b.abs().max()), 1e-20)
+    err = float((a - b).abs().max()) / scale
+    assert err <= tol, (what, err)
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride
+    (2, 9, 13, 64, 64, 3, 1),
+    (1, 16, 24, 64, 128, 3, 2),
+    (2, 7, 11, 128, 128, 3, 1),
+    (1, 5, 6, 256, 512, 3, 2),
+    (2, 8, 8, 64, 128, 1, 1),
+    (1, 9, 7, 128, 256, 1, 2),
+    (3, 6, 10, 512, 128, 1, 1),
+    (1, 33, 17, 128, 128, 3, 1),
+    (1, 1, 2, 512, 512, 3, 1),
+]
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(ops, N, H, W, Cin, Cout, k, s):
+    x = rnd(N, H, W, Cin, seed=1)
+    w = cl(rnd(Cout, Cin, k, k, seed=2, scale=0.05))
+    pad = k // 2
+    y_ref = E.conv_fwd(x, w, s, pad)
+    y = ops.conv_fwd(x.to(DEV), cl(w.to(DEV)), s, pad)
+    close(y, y_ref, what="fwd")
+    dy = rnd(*y_ref.shape, seed=3)
+    wp_ref = E.pack_dgrad_weight(w)
+    wp = ops.pack_dgrad_weight(cl(w.to(DEV)))
+    close(wp, wp_ref, 0.0, "pack")
+    gx_ref = E.conv_dgrad(dy, wp_ref, (H, W), s, pad)
+    gx = ops.conv_dgrad(dy.to(DEV), wp, (H, W), s, pad)
+    close(gx, gx_ref, what="dgrad")
+    base = rnd(N, H, W, Cin, seed=4)
+    acc = base.to(DEV).clone()
+    ops.conv_dgrad(dy.to(DEV), wp, (H, W), s, pad, out=acc, accumulate=True)
+    close(acc, base + gx_ref, what="dgrad accumulate")
+    dw_ref = torch.empty_like(w)
+    E.conv_wgrad(x, dy, dw_ref, s, pad, False)
+    dw = torch.empty_like(cl(w.to(DEV)))
+    ops.conv_wgrad(x.to(DEV), dy.to(DEV), dw, s, pad, False)
+    close(dw, dw_ref, 5e-5, "wgrad")
+    ops.conv_wgrad(x.to(DEV), dy.to(DEV), dw, s, pad, True)
+    close(dw, 2 * dw_ref, 5e-5, "wgrad accumulate")
+
+
+def test_conv_seg_head_19_classes_bias_and_padded_stride(ops):
+    x = rnd(2, 10, 12, 128, seed=5)
+    w = cl(rnd(19, 128, 1, 1, seed=6, scale=0.1))
+    b = rnd(19, seed=7)
+    y = ops.conv_fwd(x.to(DEV), cl(w.to(DEV)), 1, 0, bias=b.to(DEV), dst_cs=20)
+    ref = E.conv_fwd(x, w, 1, 0, bias=b, dst_cs=20)
+    close(y, ref, what="fwd cs20")
+    assert float(y[..., 19].abs().max()) == 0.0
+    dy = torch.zeros(2, 10, 12, 20)
+    dy[..., :19] = rnd(2, 10, 12, 19, seed=8)
+    dw = torch.empty_like(cl(w.to(DEV)))
+    ops.conv_wgrad(x.to(DEV), dy.to(DEV), dw, 1, 0, False)
+    dref = torch.empty_like(w)
+    E.conv_wgrad(x, dy, dref, 1, 0, False)
+    close(dw, dref, 5e-5, "wgrad cs20")
+    wpad = torch.zeros(128, 1, 1, 20)
+    wpad[..., :19] = E.pack_dgrad_weight(w)
+    gx = ops.conv_dgrad(dy.to(DEV), wpad.to(DEV), (10, 12), 1, 0)
+    close(gx, E.conv_dgrad(dy, E.pack_dgrad_weight(w), (10, 12), 1, 0), what="dgrad cs20")
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 48), (1, 37, 29), (1, 8, 6)])
+def test_stem_conv_and_wgrad(ops, N, H, W):
+    p = torch.zeros(N, H, W, 4)
+    p[..., :3] = rnd(N, H, W, 3, seed=9)
+    w = cl(rnd(64, 3, 7, 7, seed=10, scale=0.1))
+    wp = ops.pack_stem_weight(cl(w.to(DEV)))
+    close(wp, E.pack_stem_weight(w), 0.0, "pack stem")
+    y = ops.stem_conv(p.to(DEV), wp)
+    yref = E.stem_conv(p, E.pack_stem_weight(w))
+    close(y, yref, what="stem fwd")
+    dy = rnd(*yref.shape, seed=11)
+    dwp = torch.empty(64, 7, 8, 4, device=DEV)
+    ops.stem_wgrad(p.to(DEV), dy.to(DEV), dwp, False)
+    dref = torch.empty(64, 7, 8, 4)
+    E.stem_wgrad(p, dy, dref, False)
+    got = ops.unpack_stem_weight(dwp, cl(w.to(DEV)))
+    close(got, E.unpack_stem_weight(dref, w), 5e-5, "stem wgrad")
+
+
+def test_linear_and_transpose(ops):
+    x, w, b = rnd(37, 128, seed=12), rnd(128, 128, seed=13, scale=0.1), rnd(128, seed=14)
+    close(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)), E.linear(x, w, b), what="linear")
+    close(ops.transpose(x.to(DEV)), x.t(), 0.0, "transpose")
+    dy = rnd(37, 128, seed=15)
+    dw = torch.empty(128, 128, device=DEV)
+    ops.linear_wgrad(x.to(DEV), dy.to(DEV), dw)
+    close(dw, dy.t() @ x, 5e-5, "linear wgrad")
+
+
+@pytest.mark.parametrize("rows,C,B", [(1000, 64, 1), (77, 128, 1), (4096, 512, 1), (600, 20, 1), (300, 128, 4)])
+def test_colsum(ops, rows, C, B):
+    x = rnd(B * rows, C, seed=16) + 0.5
+    close(ops.colsum(x.to(DEV), B=B, scale=0.5), E.colsum(x, B=B, scale=0.5), 1e-5, "colsum")
+
+
+def test_batchnorm_forward_backward(ops):
+    C, rows = 64, 2 * 9 * 7
+    y = rnd(2, 9, 7, C, seed=17) * 2 + 1
+    gamma, beta = rnd(C, seed=18) * 0.1 + 1, rnd(C, seed=19) * 0.1
+    rm, rv = rnd(C, seed=20) * 0.05, rnd(C, seed=21).abs() + 1
+    rm_d, rv_d = rm.to(DEV), rv.to(DEV)
+    rm_c, rv_c = rm.clone(), rv.clone()
+    sums = ops.colsum(y.to(DEV).reshape(-1, C))
+    bn = ops.bn_finalize(sums, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, rows, True)
+    bn_ref = E.bn_finalize(E.colsum(y.reshape(-1, C)), gamma, beta, rm_c, rv_c, rows, True)
+    close(bn, bn_ref, 2e-5, "bn params")
+    close(rm_d, rm_c, 2e-6, "running mean"); close(rv_d, rv_c, 2e-5, "running var")
+    ops.bn_ema_again(bn, rm_d, rv_d, rows)
+    E.bn_ema_again(bn_ref, rm_c, rv_c, rows)
+    close(rm_d, rm_c, 2e-6, "running mean 2"); close(rv_d, rv_c, 2e-5, "running var 2")
+    bn_eval = ops.bn_finalize(None, gamma.to(DEV), beta.to(DEV), rm_d, rv_d, rows, False)
+    close(bn_eval, E.bn_finalize(None, gamma, beta, rm_c, rv_c, rows, False), 2e-5, "bn eval")
+    r = rnd(2, 9, 7, C, seed=22)
+    bn2_ref = E.bn_finalize(E.colsum(r.reshape(-1, C)), gamma, beta, rm_c.clone(), rv_c.clone(), rows, True)
+    yd, rd, bnd, bn2d = y.to(DEV), r.to(DEV), bn_ref.to(DEV), bn2_ref.to(DEV)
+    for kw_ref, kw in [(dict(), dict()), (dict(r=r), dict(r=rd)), (dict(r=r, bn2=bn2_ref), dict(r=rd, bn2=bn2d)),
+                       (dict(relu=False), dict(relu=False))]:
+        close(ops.bn_act(yd, bnd, **kw), E.bn_act(y, bn_ref, **kw_ref), 2e-6, f"bn_act {list(kw)}")
+    g = rnd(2, 9, 7, C, seed=23)
+    out = E.bn_act(y, bn_ref, r=r)
+    for name, kw_ref, kw in [("relu", dict(relu=True), dict(relu=True)),
+                             ("masksrc", dict(masksrc=out, want_gm=True), dict(masksrc=out.to(DEV), want_gm=True)),
+                             ("plain", dict(), dict())]:
+        dg_r, db_r = torch.zeros(C), torch.zeros(C)
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        dy_r, gm_r = E.bn_bwd(g, y, bn_ref, gamma, dgamma=dg_r, dbeta=db_r, **kw_ref)
+        dy, gm = ops.bn_bwd(g.to(DEV), yd, bnd, gamma.to(DEV), dgamma=dg, dbeta=db, **kw)
+        close(dy, dy_r, 2e-5, f"bn_bwd dy {name}")
+        close(dg, dg_r, 2e-5, f"dgamma {name}"); close(db, db_r, 2e-5, f"dbeta {name}")
+        if gm_r is not None:
+            close(gm, gm_r, 0.0, "gm")
+    # accumulate into a slice + accumulate params
+    base = rnd(4, 9, 7, C, seed=24)
+    acc = base.to(DEV).clone()
+    dg = torch.ones(C, device=DEV); db = torch.ones(C, device=DEV)
+    ops.bn_bwd(g.to(DEV), yd, bnd, gamma.to(DEV), relu=True, dy_out=acc[:2], acc_dy=True, dgamma=dg, dbeta=db, acc_param=True)
+    dg_r, db_r = torch.ones(C), torch.ones(C)
+    dy_r, _ = E.bn_bwd(g, y, bn_ref, gamma, relu=True, dgamma=dg_r, dbeta=db_r, acc_param=True)
+    close(acc[:2], base[:2] + dy_r, 2e-5, "acc dy"); close(acc[2:], base[2:], 0.0, "untouched")
+    close(dg, dg_r, 2e-5, "acc dgamma")
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 32, 64), (1, 37, 50), (1, 9, 10)])
+def test_normalize_pyramid(ops, N, H, W):
+    img = rnd(N, 3, H, W, seed=25).abs() * 100
+    mean, std = torch.tensor([73.15, 82.90, 72.3]), torch.tensor([47.67, 48.49, 47.73])
+    got = ops.normalize_pyramid(img.to(DEV), mean.to(DEV), std.to(DEV))
+    ref = E.normalize_pyramid(img, mean, std)
+    for a, b in zip(got, ref):
+        close(a, b, 2e-6, "pyramid level")
+
+
+@pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 17, 9), (1, 3, 3)])
+def test_bn_relu_maxpool_fwd_bwd(ops, N, H, W):
+    C = 64
+    y = rnd(N, H, W, C, seed=26)
+    bn = torch.stack([rnd(C, seed=27), rnd(C, seed=28) * 0.3, torch.zeros(C), torch.ones(C)])
+    out, idx = ops.bn_relu_maxpool(y.to(DEV), bn.to(DEV))
+    oref, iref = E.bn_relu_maxpool(y, bn)
+    close(out, oref, 1e-6, "pool fwd")
+    g = rnd(*oref.shape, seed=29) * (oref > 0)      # positions with a zero maximum are ties; relu kills them anyway
+    close(ops.maxpool_bwd(g.to(DEV), idx, H, W), E.maxpool_bwd(g, iref, H, W), 1e-6, "pool bwd")
+
+
+@pytest.mark.parametrize("IH,IW,OH,OW", [(4, 8, 8, 16), (3, 5, 6, 10), (2, 3, 3, 5), (1, 2, 2, 3), (5, 7, 9, 12)])
+def test_upsample_add_and_adjoint(ops, IH, IW, OH, OW):
+    N, C = 2, 128
+    x = rnd(N, IH, IW, C, seed=30)
+    sk = [rnd(N, OH, OW, C, seed=31 + i) for i in range(3)]
+    for n in (1, 2, 3):
+        close(ops.upsample_add(x.to(DEV), [s.to(DEV) for s in sk[:n]], OH, OW), E.upsample_add(x, sk[:n], OH, OW), 2e-6,
+              f"upsample_add {n}")
+    g = rnd(N, OH, OW, C, seed=35)
+    close(ops.upsample_bwd(g.to(DEV), IH, IW), E.upsample_bwd(g, IH, IW), 1e-5, "upsample bwd")
+    base = rnd(N, IH, IW, C, seed=36)
+    acc = base.to(DEV).clone()
+    ops.upsample_bwd(g.to(DEV), IH, IW, out=acc, accumulate=True)
+    close(acc, base + E.upsample_bwd(g, IH, IW), 1e-5, "upsample bwd acc")
+
+
+@pytest.mark.parametrize("IH,IW,OH,OW", [(8, 16, 32, 64), (30, 50, 120, 200), (7, 5, 27, 21)])
+def test_logits_upsample_and_adjoint(ops, IH, IW, OH, OW):
+    x = torch.zeros(2, IH, IW, 20)
+    x[..., :19] = rnd(2, IH, IW, 19, seed=37)
+    close(ops.upsample_to_nchw(x.to(DEV), 19, OH, OW), E.upsample_to_nchw(x, 19, OH, OW), 2e-6, "logits up")
+    g = rnd(2, 19, OH, OW, seed=38)
+    close(ops.upsample_to_nchw_bwd(g.to(DEV), IH, IW, 20), E.upsample_to_nchw_bwd(g, IH, IW, 20), 1e-5, "logits up bwd")
+
+
+@pytest.mark.parametrize("mode", ["full", "plain_focal", "no_class_weights", "no_EDT", "ce"])
+def test_seg_loss(ops, mode):
+    g = np.random.default_rng(39)
+    lg = rnd(2, 19, 24, 40, seed=40) * 2
+    tgt = torch.from_numpy(g.integers(0, 19, size=(2, 24, 40)).astype(np.int64))
+    tgt[:, :2, :] = 255
+    ldw = torch.from_numpy(g.random((2, 24, 40)).astype(np.float32))
+    ldw[tgt == 255] = 0
+    cw = torch.from_numpy((1.0 / np.log(1.1 + g.random(19) * 0.2)).astype(np.float32))
+    t_ref, t_dev = tgt.clone(), tgt.clone().to(DEV)
+    args = (None, None) if mode == "ce" else (ldw, cw)
+    out_r, grad_r = E.seg_loss(lg, t_ref, *args, mode)
+    out, grad = ops.seg_loss(lg.to(DEV), t_dev, *(a.to(DEV) if a is not None else None for a in args), mode)
+    close(out, out_r, 1e-5, "loss/count")
+    close(grad, grad_r, 1e-5, "grad")
+    assert torch.equal(t_dev.cpu(), t_ref)                      # in-place 255 -> 0 for focal modes only
+    ops.scale_inplace(grad, torch.tensor([1.2], device=DEV), out[2:3])
+    close(grad, grad_r * 1.2 * out_r[2], 1e-5, "scaled grad")
+
+
+def test_seg_loss_no_valid_pixels(ops):
+    lg = rnd(1, 19, 4, 4, seed=41)
+    t = torch.full((1, 4, 4), 255, dtype=torch.int64, device=DEV)
+    out, grad = ops.seg_loss(lg.to(DEV), t, torch.zeros(1, 4, 4, device=DEV), torch.ones(19, device=DEV), "full")
+    assert out.cpu().tolist() == [0.0, 0.0, 0.0] and int(t.max()) == 0
+
+
+@pytest.mark.parametrize("h,w,scale", [(12, 20, 4), (33, 47, 4), (64, 64, 2)])
+def test_anchor_keys_and_select(ops, h, w, scale):
+    g = np.random.default_rng(42)
+    N, C = 3, 19
+    lg = torch.zeros(N, h, w, 20)
+    lg[..., :19] = rnd(N, h, w, 19, seed=43)
+    labels = torch.from_numpy(g.integers(0, 7, size=(N, h * scale, w * scale)).astype(np.int64))
+    labels[:, :5, :] = 255
+    key_r, hist_r = E.anchor_keys_raw(lg, N, h, w, 20, C, labels)
+    key, hist = ops.anchor_keys_raw(lg.to(DEV), N, h, w, 20, C, labels.to(DEV))
+    assert torch.equal(key.cpu(), key_r) and torch.equal(hist.cpu(), hist_r)
+    counts = hist_r.sum(1)
+    req = []
+    for n in range(N):
+        for k in range(2 * C):
+            c = int(counts[n, k])
+            for r in {0, c // 2, c - 1, c}:
+                if r >= 0:
+                    req.append([n, k, r])
+    req = torch.tensor(req, dtype=torch.int32)
+    sel = ops.anchor_select(key, hist, req.to(DEV), C)
+    assert torch.equal(sel.cpu(), E.anchor_select(key_r, hist_r, req, C))
+
+
+def test_gather_scatter_rows(ops):
+    feat = rnd(500, 128, seed=44)
+    idx = torch.from_numpy(np.random.default_rng(45).permutation(500)[:37].astype(np.int32))
+    X = ops.gather_rows(feat.to(DEV), idx.to(DEV))
+    close(X, feat[idx.long()], 0.0, "gather")
+    gf = rnd(500, 128, seed=46)
+    gfd = gf.to(DEV).clone()
+    ops.scatter_add_rows(X, idx.to(DEV), gfd)
+    ref = gf.clone()
+    ref[idx.long()] += feat[idx.long()]
+    close(gfd, ref, 1e-7, "scatter")
+
+
+@pytest.mark.parametrize("A,mode", [(8, 1), (64, 1), (76, 0), (304, 0), (608, 0), (33, 0)])
+def test_contrast_fwd_bwd(ops, A, mode):
+    g = np.random.default_rng(47 + A)
+    X = rnd(A, 128, seed=48 + A) * 0.7
+    if mode == 0:
+        T = A // 2
+        y = torch.from_numpy(np.tile(g.integers(0, 6, size=T), 2).astype(np.float32)) if A % 2 == 0 else \
+            torch.from_numpy(g.integers(0, 3, size=A).astype(np.float32))
+    else:
+        y = torch.from_numpy(np.tile(g.integers(0, 3, size=A // 2), 2).astype(np.float32))
+    loss_r, dX_r = E.contrast_fwd_bwd(X.double(), y.double(), mode)
+    loss, dX = ops.contrast_fwd_bwd(X.to(DEV), y.to(DEV), mode)
+    close(loss, loss_r, 2e-5, "loss")
+    close(dX, dX_r, 2e-4, "dX")
+
+
+def test_adam_and_small_helpers(ops):
+    p, gr = cl(rnd(64, 64, 3, 3, seed=50)), cl(rnd(64, 64, 3, 3, seed=51))
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    pd, gd, md, vd = (cl(t.to(DEV)) for t in (p, gr, m, v))
+    for step in (1, 2, 3):
+        E.adam_step(p, gr, m, v, 1e-4, 0.9, 0.99, 1e-8, 2.5e-5, step)
+        ops.adam_step(pd, gd, md, vd, 1e-4, 0.9, 0.99, 1e-8, 2.5e-5, step)
+    close(pd, p, 1e-6, "adam p"); close(vd, v, 1e-5, "adam v")
+    a, b = rnd(1000, seed=52), rnd(1000, seed=53)
+    ad = a.to(DEV).clone()
+    ops.axpy(ad, b.to(DEV), 0.25)
+    close(ad, a + 0.25 * b, 1e-6, "axpy")
+    close(ops.sum_scalar(a.to(DEV), 0.5), a.double().sum().float().reshape(1) * 0.5, 1e-5, "sum")
+    close(ops.relu_bwd(a.to(DEV), b.to(DEV)), a * (b > 0), 0.0, "relu bwd")
+    gt, vv = rnd(2, 3, 5, 128, seed=54), rnd(2, 128, seed=55)
+    gd = gt.to(DEV).clone()
+    ops.add_rowvec_bcast(gd, vv.to(DEV), 0.1)
+    close(gd, gt + 0.1 * vv.view(2, 1, 1, 128), 1e-6, "bcast")
+
+
+def test_ops_refuse_cpu_tensors(ops):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv_fwd(torch.zeros(1, 4, 4, 64), cl(torch.zeros(64, 64, 3, 3)), 1, 1)

@@ -25,9 +25,9 @@ def close(a, b, rtol=RTOL, atol=None):
 
 
 STEP_CASES = [
-    ("step_supcon_pixel_focal_b2_64x128.npz", "supcon_pixelcontrast_focal", dict(b=2, h=64, w=128, seed=10, two=True), 123),
-    ("step_pixel_focal_b2_96x160.npz", "pixelcontrast_focal", dict(b=2, h=96, w=160, seed=11, two=False), 7),
-    ("step_ce_b2_64x128.npz", "crossentropy", dict(b=2, h=64, w=128, seed=12, two=False), 1),
+    ("step_supcon_pixel_focal_b2_256x512.npz", "supcon_pixelcontrast_focal", dict(b=2, h=256, w=512, seed=10, two=True, cell=32), 123),
+    ("step_pixel_focal_b2_200x328.npz", "pixelcontrast_focal", dict(b=2, h=200, w=328, seed=11, two=False, cell=24), 7),
+    ("step_ce_b2_256x512.npz", "crossentropy", dict(b=2, h=256, w=512, seed=12, two=False, cell=32), 1),
 ]
 
 
@@ -37,7 +37,7 @@ def test_train_step_matches_reference(golden_dir, fname, criterion, shape, rng_s
     state = O.make_state(seed=1)
     proj = O.make_proj(seed=2)
     img, labels, ldw, weather, cw = O.synthetic_batch(shape["b"], shape["h"], shape["w"], seed=shape["seed"],
-                                                      two_crops=shape["two"], cell=16)
+                                                      two_crops=shape["two"], cell=shape["cell"])
     opt = O.Adam(state)
     torch.manual_seed(rng_seed)
     labels = labels.clone()
@@ -46,9 +46,9 @@ def test_train_step_matches_reference(golden_dir, fname, criterion, shape, rng_s
     for k in ("supcon", "pixel", "seg", "ce"):
         if out[k] is not None:
             close(out[k], g[k])
-    close(out["before"], g["before"])
-    close(out["fine_feat"], g["fine_feat"])
-    close(out["seg_logits"][:, :, ::4, ::4], g["seg_logits_sub"])
+    close(out["before"][:, :, ::2, ::2], g["before_sub"])
+    close(out["fine_feat"][:, :, ::4, ::4], g["fine_feat_sub"])
+    close(out["seg_logits"][:, :, ::8, ::8], g["seg_logits_sub"])
     assert np.array_equal(out["seg_logits"].argmax(1).numpy().astype(np.uint8), g["seg_argmax"])
     if criterion != "crossentropy":
         # focal loss mutates the caller's labels in place (utils/loss.py:43)
@@ -56,9 +56,8 @@ def test_train_step_matches_reference(golden_dir, fname, criterion, shape, rng_s
     if "anchors" in out:
         img_idx, cls, pix = out["anchors"]
         assert np.array_equal(cls.numpy().astype(np.float32), g["anchor_y"])
-        ff = torch.from_numpy(g["fine_feat"])
         b0 = shape["b"]
-        x = ff[:b0].permute(0, 2, 3, 1).reshape(b0, -1, 128)
+        x = out["fine_feat"][:b0].permute(0, 2, 3, 1).reshape(b0, -1, 128)
         close(x[img_idx.unsqueeze(1), pix], g["anchor_x"])
     names = [str(s) for s in g["grad_names"]]
     for k, n, s in zip(names, g["grad_norms"], g["grad_sums"]):
@@ -88,7 +87,7 @@ def test_train_step_matches_reference(golden_dir, fname, criterion, shape, rng_s
 def test_bn_update_multiplicity(golden_dir):
     """block BNs are updated 6x per step (3 levels x checkpoint
     recompute), stem / downsample / decoder / head BNs once per call."""
-    g = load(golden_dir, "step_ce_b2_64x128.npz")
+    g = load(golden_dir, "step_ce_b2_256x512.npz")
     assert int(g["post::feature_extractor.layer1.0.bn1.num_batches_tracked"]) == 6
     assert int(g["post::feature_extractor.layer2.0.downsample.1.num_batches_tracked"]) == 3
     assert int(g["post::feature_extractor.bn1_0.num_batches_tracked"]) == 1
@@ -174,3 +173,19 @@ def test_sampling_edge_cases():
     torch.manual_seed(0)
     img_idx, cls, pix = O.hard_anchor_sampling_indices(lab, pred)
     assert pix.shape == (1, 2) and int(cls[0]) == 0
+
+
+def test_fp32_gradient_conditioning():
+    """Documents why the step fixtures use >= 200x328 inputs: with 1x2 .. 3x5 deep maps (96x160 input) the oracle's
+    own BatchNorm gradients differ by >5e-4 (relative norm) between an fp32 and an fp64 evaluation."""
+    img, labels, ldw, weather, cw = O.synthetic_batch(2, 96, 160, seed=11, two_crops=False, cell=16)
+    res = {}
+    for dt in (torch.float32, torch.float64):
+        state = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in O.make_state(seed=1).items()}
+        torch.manual_seed(7)
+        _, grads, _ = O.train_step(state, [p.to(dt) for p in O.make_proj(2)], None, img.to(dt), labels.clone(),
+                                   ldw.to(dt), weather, cw.to(dt), "pixelcontrast_focal", 2)
+        res[dt] = grads
+    worst = max(abs(float(a.norm()) - float(res[torch.float64][k].norm())) / float(res[torch.float64][k].norm())
+                for k, a in res[torch.float32].items() if a is not None)
+    assert 5e-4 < worst < 2e-2, worst

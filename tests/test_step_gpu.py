@@ -1,0 +1,197 @@
+"""GPU parity tests proper: the HIP train step (through the C ABI) against
+  * the golden vectors produced by the reference (tests/golden/*.npz), and
+  * the CPU oracle on other seeded inputs (odd sizes, every criterion),
+plus size-independent properties at a larger size (finite losses, loss decreases under training).
+Tolerance (north star): losses / logits / features within 1e-3 relative to the tensor's max in fp32; class-id
+argmax equal except at numerical near-ties (checked against the logit gap); gradients 1e-2 relative L2 (the
+resolution of fp32 gradients on these fixtures, see tests/test_host_logic_cpu.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import swiftnet_oracle as O
+from step_check import check_argmax, close, close_l2, run_and_check_step
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+RTOL = 1e-3
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from dcs_amd import lib
+    lib.load()
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def build(criterion, batch_size=2, cw=None):
+    from dcs_amd.trainer import TrainStep, make_opts
+    ts = TrainStep(make_opts(criterion=criterion, batch_size=batch_size), class_weight=cw, device=DEV)
+    ts.model.load_state_dict(O.make_state(seed=1), strict=True)
+    proj = O.make_proj(seed=2)
+    with torch.no_grad():
+        p = ts.supcon_criterion.projection
+        for dst, src in zip((p[0].weight, p[0].bias, p[2].weight, p[2].bias), proj):
+            dst.copy_(src)
+    return ts
+
+
+CASES = [
+    ("step_supcon_pixel_focal_b2_256x512.npz", "supcon_pixelcontrast_focal", dict(b=2, h=256, w=512, seed=10, two=True, cell=32), 123),
+    ("step_pixel_focal_b2_200x328.npz", "pixelcontrast_focal", dict(b=2, h=200, w=328, seed=11, two=False, cell=24), 7),
+    ("step_ce_b2_256x512.npz", "crossentropy", dict(b=2, h=256, w=512, seed=12, two=False, cell=32), 1),
+]
+
+
+@pytest.mark.parametrize("fname,criterion,shape,rng_seed", CASES)
+def test_train_step_matches_reference_golden(golden_dir, fname, criterion, shape, rng_seed):
+    run_and_check_step(build(criterion), load(golden_dir, fname), criterion, shape, rng_seed, rtol=RTOL, grad_rtol=1e-2)
+
+
+def test_eval_forward_matches_reference_golden(golden_dir):
+    g = load(golden_dir, "eval_fwd_b1_120x200.npz")
+    ts = build("crossentropy")
+    ts.model.eval()
+    img = O.synthetic_batch(1, 120, 200, seed=13)[0]
+    with torch.no_grad():
+        seg, before, ff, ff0 = ts.model(img.to(DEV))
+    close(before, g["before"], RTOL, "before")
+    close(ff, g["fine_feat"], RTOL, "fine_feat")
+    close(seg[:, :, ::4, ::4], g["seg_logits_sub"], RTOL, "seg")
+    check_argmax(seg, g["seg_argmax"], RTOL)
+    assert seg.is_contiguous() and tuple(seg.shape) == (1, 19, 120, 200)
+
+
+@pytest.mark.parametrize("criterion,two,b,h,w", [
+    ("supcon_focal", True, 2, 224, 352), ("supcon_simclr_pixelcontrast_focal", True, 1, 256, 256),
+    ("supcon_crossentropy", True, 2, 192, 320), ("focal", False, 3, 160, 416), ("supcon_simclr_cross_entropy", True, 2, 192, 256)])
+def test_train_step_matches_oracle(criterion, two, b, h, w):
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=70 + b, two_crops=two, cell=32)
+    ts = build(criterion, batch_size=b, cw=cw)
+    s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+    torch.manual_seed(9)
+    out = ts.step((s0, dict(left=img[b:])) if two else s0, do_optimizer_step=False)
+    state, proj = O.make_state(seed=1), O.make_proj(seed=2)
+    torch.manual_seed(9)
+    ref, grads, gproj = O.train_step(state, proj, None, img, labels.clone(), ldw, weather, cw, criterion, b)
+    close(out["total"].reshape(()), ref["total"], RTOL, "total")
+    close(out["fine_feat"], ref["fine_feat"], RTOL, "fine_feat")
+    close(out["left_seg"], ref["seg_logits"], RTOL, "seg")
+    check_argmax(out["left_seg"], ref["seg_logits"].argmax(1).numpy().astype(np.uint8), RTOL)
+    params = dict(ts.model.named_parameters())
+    for k, gref in grads.items():
+        if gref is None:
+            assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
+        else:
+            close_l2(params[k].grad, gref.numpy(), 1e-2, k)
+    sd = ts.model.state_dict()
+    for k, v in state.items():
+        if "running_" in k:
+            close(sd[k], v.numpy(), RTOL, k)
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v), k
+
+
+def test_loss_units_match_reference_golden(golden_dir):
+    from dcs_amd.losses import BoundaryAwareFocalLoss, PixelContrastLoss, SemsegCrossEntropy, SupConLoss
+    from dcs_amd.trainer import make_opts
+    g = load(golden_dir, "loss_units.npz")
+    # pixel contrast (feats given NCHW-contiguous here: exercises the layout conversion path)
+    feats = torch.from_numpy(g["pix_feats"]).to(DEV).requires_grad_(True)
+    pc = PixelContrastLoss(device=DEV)
+    torch.manual_seed(99)
+    loss = pc(feats, labels=torch.from_numpy(g["pix_labels"]).long().to(DEV), predict=torch.from_numpy(g["pix_logits"]).to(DEV))
+    loss.backward()
+    close(loss, g["pix_loss"], RTOL, "pixel loss")
+    close_l2(feats.grad, g["pix_grad_feats"], 2e-3, "pixel grad")
+    assert np.array_equal(np.asarray(pc.last_anchors[1], dtype=np.float32), g["pix_anchor_y"])
+    # supcon / simclr
+    sc = SupConLoss(device=DEV, opts=make_opts())
+    proj = O.make_proj(seed=5)
+    with torch.no_grad():
+        p = sc.projection
+        for dst, src in zip((p[0].weight, p[0].bias, p[2].weight, p[2].bias), proj):
+            dst.copy_(src)
+    f = torch.from_numpy(g["sup_feats"]).to(DEV).requires_grad_(True)
+    l1 = sc(f, class_labels=torch.from_numpy(g["sup_weather"]).to(DEV))
+    l1.backward()
+    close(l1, g["sup_loss"], RTOL, "supcon")
+    close_l2(f.grad, g["sup_grad_feats"], 2e-3, "supcon grad feats")
+    close_l2(sc.projection[0].weight.grad, g["sup_grad_w1"], 2e-3, "supcon grad w1")
+    close_l2(sc.projection[2].bias.grad, g["sup_grad_b2"], 2e-3, "supcon grad b2")
+    f2 = torch.from_numpy(g["sup_feats"]).to(DEV).requires_grad_(True)
+    l2 = sc(f2, class_labels=None)
+    l2.backward()
+    close(l2, g["simclr_loss"], RTOL, "simclr")
+    close_l2(f2.grad, g["simclr_grad_feats"], 2e-3, "simclr grad")
+    # focal variants, low-res logits, CE
+    cw = torch.from_numpy(g["foc_cw"])
+    ldw = torch.from_numpy(g["foc_ldw"]).to(DEV)
+    for variant in ("full", "plain_focal", "no_class_weights", "no_EDT"):
+        o = make_opts(criterion="plain_focal" if variant == "plain_focal" else "focal",
+                      no_class_weights=variant == "no_class_weights", no_EDT=variant == "no_EDT")
+        crit = BoundaryAwareFocalLoss(gamma=0.5, num_classes=19, ignore_id=255, weight=cw, device=DEV, opts=o)
+        lg = torch.from_numpy(g["foc_logits"]).to(DEV).requires_grad_(True)
+        t = torch.from_numpy(g["foc_target"]).long().to(DEV)
+        lv = crit(lg, t, {"label_distance_weight": ldw})
+        lv.backward()
+        close(lv, g[f"foc_loss_{variant}"], RTOL, variant)
+        close_l2(lg.grad, g[f"foc_grad_{variant}"], 2e-3, variant + " grad")
+        assert int(t.max()) < 255
+    crit = BoundaryAwareFocalLoss(gamma=0.5, num_classes=19, ignore_id=255, weight=cw, device=DEV, opts=make_opts(criterion="focal"))
+    lr_ = torch.from_numpy(g["foc_lr_logits"]).to(DEV).requires_grad_(True)
+    lv = crit(lr_, torch.from_numpy(g["foc_target"]).long().to(DEV), {"label_distance_weight": ldw})
+    lv.backward()
+    close(lv, g["foc_lr_loss"], RTOL, "focal low-res")
+    close_l2(lr_.grad, g["foc_lr_grad"], 2e-3, "focal low-res grad")
+    lg = torch.from_numpy(g["foc_logits"]).to(DEV).requires_grad_(True)
+    lce = SemsegCrossEntropy()(lg, torch.from_numpy(g["foc_target"]).long().to(DEV))
+    lce.backward()
+    close(lce, g["ce_loss"], RTOL, "ce")
+    close_l2(lg.grad, g["ce_grad"], 2e-3, "ce grad")
+    # weather classifier
+    from dcs_amd.model import WeatherClassifier
+    clf = WeatherClassifier(make_opts(), 4).to(DEV)
+    with torch.no_grad():
+        clf.fc.weight.copy_(torch.from_numpy(g["clf_w"])); clf.fc.bias.copy_(torch.from_numpy(g["clf_b"]))
+    close(clf(torch.from_numpy(g["sup_feats"]).to(DEV)), g["clf_out"], RTOL, "weather clf")
+
+
+def test_sampler_edge_cases():
+    from dcs_amd.losses import PixelContrastLoss
+    pc = PixelContrastLoss(device=DEV)
+    feats = torch.randn(1, 128, 8, 8, device=DEV)
+    logits = torch.randn(1, 19, 8, 8, device=DEV)
+    with pytest.raises(AttributeError):                     # no class qualifies (utils/loss.py:287-288 -> :341)
+        pc(feats, labels=torch.full((1, 32, 32), 255, dtype=torch.long, device=DEV), predict=logits)
+    lab = torch.zeros((1, 32, 32), dtype=torch.long, device=DEV)
+    logits2 = logits.clone(); logits2[:, 0] = -100.0        # class 0 never predicted: all-hard class, 0 easy pixels
+    out = pc(feats, labels=lab, predict=logits2)
+    assert out.shape == () and pc.last_anchors[3] == 2      # single class -> no negatives, positives only
+    assert torch.isfinite(out)
+
+
+def test_training_reduces_loss_at_bench_like_size():
+    """Size-independent property at a larger size than the oracle handles in seconds: a few Adam steps on a
+    fixed batch reduce the total loss, everything stays finite, BN counters advance as the reference's do."""
+    b, h, w = 2, 512, 1024
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=5, two_crops=True, cell=64)
+    ts = build("supcon_pixelcontrast_focal", batch_size=b, cw=cw)
+    losses = []
+    for it in range(4):
+        s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        torch.manual_seed(it)
+        out = ts.step((s0, dict(left=img[b:])))
+        losses.append(float(out["total"]))
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    sd = ts.model.state_dict()
+    assert int(sd["feature_extractor.layer1.0.bn1.num_batches_tracked"]) == 24
+    assert int(sd["feature_extractor.bn1_0.num_batches_tracked"]) == 4
