@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the SwiftNet-RN18 doubly-contrastive TRAIN STEP on synthetic 2048x1024 batches.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--height H --width W] [--criterion C]
+
+N > 1 is launched by the driver as ``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...``
+(one rank per GPU, RCCL).  A "step" is one pass of trainer.py:62-215 (forward of both crops, the three losses,
+backward, Adam) over one synthetic batch that is already resident in HBM.  Rank 0 prints ONE JSON line.
+
+Workload at N=1 = BASELINE.json configs[2] ("C3"): B=16 labelled images (32 crops through the model) at
+2048x1024, criterion supcon_pixelcontrast_focal -- the configuration the metric is quoted on; it fits one GPU.
+Weak scaling: every rank keeps B=16.
+
+roofline: dominant kernel = the implicit-GEMM conv kernel (forward + data gradient launches, conv_gather_kernel).
+achieved = algorithmic FLOPs (2*M*taps*K*Cout per launch) / summed launch time measured with HIP
+events recorded on the launch stream during the timed steps.  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+cpu_baseline: the oracle (pure-PyTorch CPU restatement, kind "port") on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "doubly-contrastive-semseg_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="labelled images per GPU (each contributes two crops)")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--criterion", default="supcon_pixelcontrast_focal")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def device_batch(O, b, h, w, seed, two, dev):
+    """Synthetic batch built per image to bound host memory, moved to HBM once."""
+    imgs, labs, ldws, wth = [], [], [], []
+    cw = None
+    for i in range(b):
+        img, lab, ldw, weather, cw = O.synthetic_batch(1, h, w, seed=seed + i, two_crops=two, cell=64)
+        imgs.append(img); labs.append(lab); ldws.append(ldw); wth.append(weather)
+    left0 = torch.cat([im[:1] for im in imgs]).to(dev)
+    left1 = torch.cat([im[1:] for im in imgs]).to(dev) if two else None
+    return left0, left1, torch.cat(labs).to(dev), torch.cat(ldws).to(dev), torch.cat(wth).to(dev), cw
+
+
+class ConvProfiler:
+    """Records a HIP event pair (on the launch stream) around every conv launch of one kind."""
+
+    def __init__(self, ops):
+        self.ops, self.records, self.enabled = ops, [], False
+        self._orig = ops._call
+
+        def wrapped(name, *args):
+            if self.enabled and name in ("dcs_conv_gather", "dcs_conv_wgrad"):
+                g = args[4]._obj if name == "dcs_conv_gather" else args[3]._obj
+                M = g.N * g.TY * g.TX
+                flops = 2.0 * M * (147 if g.stem else g.ntaps * g.K) * g.Cout
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                self._orig(name, *args)
+                e1.record()
+                self.records.append((name, flops, e0, e1))
+            else:
+                self._orig(name, *args)
+        ops._call = wrapped
+
+    def summary(self):
+        out = {}
+        for name in ("dcs_conv_gather", "dcs_conv_wgrad"):
+            rs = [r for r in self.records if r[0] == name]
+            if not rs:
+                continue
+            ms = sum(r[2].elapsed_time(r[3]) for r in rs)
+            fl = sum(r[1] for r in rs)
+            out[name] = dict(launches=len(rs), ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
+                             avg_us=ms * 1e3 / len(rs))
+        return out
+
+
+def cpu_baseline(O, args):
+    """Oracle train step on the host cores: bounded sample = one labelled image (two crops) of the same size."""
+    torch.set_num_threads(os.cpu_count() or 1)
+    b = 1
+    two = "supcon" in args.criterion
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, args.height, args.width, seed=100, two_crops=two, cell=64)
+    state, proj = O.make_state(seed=1), O.make_proj(seed=2)
+    opt = O.Adam(state)
+    times = []
+    for it in range(1 + args.cpu_steps):
+        t0 = time.perf_counter()
+        O.train_step(state, proj, opt, img, labels.clone(), ldw, weather, cw, args.criterion, b)
+        times.append(time.perf_counter() - t0)
+    sec = sum(times[1:]) / max(len(times) - 1, 1)
+    return {"value": b / sec, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{args.cpu_steps} timed steps (1 warm-up) of B={b} labelled image ({2 if two else 1} crops) at "
+                      f"{args.width}x{args.height}, {args.criterion}, oracle/swiftnet_oracle.py on torch CPU"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import dcs_amd.ops as ops
+    from dcs_amd.trainer import TrainStep, make_opts
+    from oracle import swiftnet_oracle as O          # synthetic inputs + CPU baseline only (never on the GPU path)
+
+    two = "supcon" in args.criterion
+    b = args.batch
+    left0, left1, labels, ldw, weather, cw = device_batch(O, b, args.height, args.width, 1000 * rank, two, dev)
+    torch.manual_seed(1)
+    ts = TrainStep(make_opts(criterion=args.criterion, batch_size=b * world), class_weight=cw, device=dev)
+    if world > 1:
+        from dcs_amd.dist import DataParallelStep
+        stepper = DataParallelStep(ts, rank, world)
+    else:
+        stepper = ts
+    torch.manual_seed(1234 + rank)
+    prof = ConvProfiler(ops)
+
+    def one_step():
+        s0 = dict(left=left0, label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        return stepper.step((s0, dict(left=left1)) if two else s0)
+
+    for _ in range(args.warmup):
+        one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    prof.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss = float(out["total"])
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = b * world * args.steps / dt
+        ps = prof.summary()
+        g = ps.get("dcs_conv_gather", dict(tflops=0.0, avg_us=0.0, launches=0, ms=0.0))
+        wg = ps.get("dcs_conv_wgrad", dict(tflops=0.0, avg_us=0.0, launches=0, ms=0.0))
+        crops = 2 if two else 1
+        line = {
+            "metric": "images/sec (2048x1024) SwiftNet-RN18 train step",
+            "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C3: SwiftNet-RN18 pyramid + {args.criterion}, B={b}/GPU labelled images x {crops} crops "
+                                   f"at {args.width}x{args.height}, fwd+losses+bwd+Adam",
+                       "global_batch": b * world, "crops_per_image": crops, "parallelism": f"dp{world}",
+                       "model_images_per_sec": value * crops,
+                       "conv_tflops_per_gpu_whole_step": value * crops * 769.2e9 * (args.height * args.width / (1024 * 2048)) / 1e12 / world,
+                       "final_loss": loss},
+            "roofline": {"bound": "mfma", "achieved": g["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": g["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "kernel": "conv_gather_kernel (conv forward + data gradient, fp32 MFMA 32x32x2)",
+                         "launches_per_step": g["launches"] // max(args.steps, 1), "avg_launch_us": g["avg_us"],
+                         "ms_per_step": g["ms"] / max(args.steps, 1),
+                         "wgrad_kernel": {"achieved": wg["tflops"], "frac": wg["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                                          "ms_per_step": wg["ms"] / max(args.steps, 1),
+                                          "launches_per_step": wg["launches"] // max(args.steps, 1)}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(O, args)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
