@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--criterion", default="supcon_pixelcontrast_focal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--conv-report", default=None, help="write a per-shape conv timing table (json lines) to this file")
     return ap.parse_args()
 
 
@@ -74,10 +75,24 @@ class ConvProfiler:
                 e0.record()
                 self._orig(name, *args)
                 e1.record()
-                self.records.append((name, flops, e0, e1))
+                key = (name, g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy, g.stem)
+                self.records.append((name, flops, e0, e1, key))
             else:
                 self._orig(name, *args)
         ops._call = wrapped
+
+    def per_shape(self):
+        agg = {}
+        for name, flops, e0, e1, key in self.records:
+            a = agg.setdefault(key, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
+        rows = []
+        for key, (n, ms, fl) in agg.items():
+            rows.append(dict(kernel=key[0], N=key[1], SH=key[2], SW=key[3], TY=key[4], TX=key[5], K=key[6], Cout=key[7],
+                             taps=key[8], sy=key[9], dsy=key[10], stem=key[11], launches=n, ms=ms,
+                             tflops=fl / (ms * 1e-3) / 1e12))
+        rows.sort(key=lambda r: -r["ms"])
+        return rows
 
     def summary(self):
         out = {}
@@ -193,6 +208,10 @@ def main():
                                           "ms_per_step": wg["ms"] / max(args.steps, 1),
                                           "launches_per_step": wg["launches"] // max(args.steps, 1)}},
         }
+        if args.conv_report:
+            with open(args.conv_report, "w") as f:
+                for r in prof.per_shape():
+                    f.write(json.dumps(r) + "\n")
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(O, args)
         print(json.dumps(line))

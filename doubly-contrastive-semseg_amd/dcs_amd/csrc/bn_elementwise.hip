@@ -67,14 +67,27 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
   }
 }
 
-__global__ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int groups, int C,
+// out[b][2][C] = scale * sum_g partial[b][g][2][C].  Block = 32 output columns x 8 group lanes; each lane sums
+// groups gl, gl+8, ... in double, then the 8 lanes are added in fixed order (deterministic).
+__global__ __launch_bounds__(256)
+void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int groups, int C,
                                     float scale) {
-  const int b = blockIdx.x;
-  for (int t = threadIdx.x; t < 2 * C; t += blockDim.x) {
-    const int which = t / C, c = t - which * C;
-    double s = 0.0;
-    for (int gi = 0; gi < groups; ++gi) s += (double)partial[(((long long)b * groups + gi) * 2 + which) * C + c];
-    out[((long long)b * 2 + which) * C + c] = (float)(s * (double)scale);
+  __shared__ double sm[8][33];
+  const int b = blockIdx.y;
+  const int col = blockIdx.x * 32 + (threadIdx.x & 31);
+  const int gl = threadIdx.x >> 5;
+  double s = 0.0;
+  if (col < 2 * C) {
+    const float* p = partial + (long long)b * groups * 2 * C + col;
+    for (int gi = gl; gi < groups; gi += 8) s += (double)p[(long long)gi * 2 * C];
+  }
+  sm[gl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (gl == 0 && col < 2 * C) {
+    double t = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
+    out[(long long)b * 2 * C + col] = (float)(t * (double)scale);
   }
 }
 
@@ -152,10 +165,11 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
                          const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
                          float* __restrict__ dy, float* __restrict__ gm_out, float* __restrict__ dgamma,
                          float* __restrict__ dbeta, long long rows, int C, int relu, int acc_dy, int acc_gm,
-                         int acc_param) {
+                         int acc_param, int training) {
   const int C4 = C >> 2;
   const long long n4 = rows * C4;
-  const float inv = (float)(1.0 / (double)rows);
+  // eval-mode BatchNorm is a fixed affine map: the batch-statistics terms vanish
+  const float inv = training ? (float)(1.0 / (double)rows) : 0.f;
   if (blockIdx.x == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
       dbeta[c] = (acc_param ? dbeta[c] : 0.f) + sums[c];
@@ -283,7 +297,8 @@ extern "C" int dcs_colsum_partial(const float* x, const float* y, const float* m
 
 extern "C" int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale, void* stream) {
   DCS_CHECK_ARG(partial && out && B > 0 && groups > 0 && C > 0);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)B), dim3(256), 0, dcs_stream(stream), partial, out, groups, C, scale);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((2 * C + 31) / 32), (unsigned)B), dim3(256), 0, dcs_stream(stream),
+                     partial, out, groups, C, scale);
   DCS_LAUNCH_RET();
 }
 
@@ -315,13 +330,13 @@ extern "C" int dcs_bn_act(const float* y, const float* bn, const float* r, const
 extern "C" int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
                                 const float* gamma, const float* sums, float* dy, float* gm_out, float* dgamma,
                                 float* dbeta, int64_t rows, int C, int relu, int acc_dy, int acc_gm, int acc_param,
-                                void* stream) {
+                                int training, void* stream) {
   DCS_CHECK_ARG(g && y && bn && rows > 0 && C > 0 && (C & 3) == 0);
   DCS_CHECK_ARG(!dy || (gamma && sums));
   DCS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || sums));
   const long long n4 = (long long)rows * (C / 4);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
-                     sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param);
+                     sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training);
   DCS_LAUNCH_RET();
 }
 

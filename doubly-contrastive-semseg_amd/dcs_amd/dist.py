@@ -1,0 +1,109 @@
+"""Data-parallel train step: one process per GPU, ``torch.distributed`` (backend "nccl" = RCCL over xGMI).
+
+The reference has no multi-process path (only ``nn.DataParallel`` on resume, utils/init_trainer.py:310-313);
+SURVEY.md 8(e) defines the MI355X design implemented here:
+
+  * the batch is sharded by image; BatchNorm statistics stay per rank (the semantics of the reference's
+    DataParallel replicas);
+  * hard anchors are SAMPLED per rank (``n_view`` depends on the local class count, utils/loss.py:290-291), then
+    the sampled pixel embeddings [A_r,128] (+labels) and the projected image embeddings [2B_r,128] (+labels)
+    are ALL-GATHERED so that both contrastive denominators run over the global batch.  Every rank evaluates the
+    full global loss and back-propagates only its own rows -- no collective in the backward of the losses;
+  * the segmentation loss is normalised by the GLOBAL count of valid pixels (all-reduce of 2 floats);
+  * parameter gradients of all ranks are SUMMED with ONE all-reduce over a flat fp32 bucket (48.2 MB for
+    ResNet-18: ~0.3-0.6 ms on xGMI against >=250 ms of backward, so no bucketing/overlap is needed);
+  * ``1/batch_size`` in the criterion (trainer.py:158) uses the GLOBAL batch size.
+
+With sum-reduction the result equals the gradient of the single global objective
+``(supcon_g + pixel_g)/B_g + 1.2 * seg_g`` evaluated with per-rank BatchNorm.
+"""
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+
+class RowGather:
+    """All-gather of a variable number of [rows, C] embeddings and their labels.
+
+    Returns (X_all [sum A_r, C], y_all [sum A_r], start) where this rank's rows are
+    X_all[start:start+A_r], ranks concatenated in rank order."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __call__(self, X: torch.Tensor, y: torch.Tensor):
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        A, Cc = X.shape
+        cnt = torch.tensor([A], device=X.device, dtype=torch.int64)
+        cnts = [torch.zeros_like(cnt) for _ in range(world)]
+        dist.all_gather(cnts, cnt, group=self.group)
+        counts = [int(c) for c in cnts]                      # one small host sync (the sampler already synced)
+        amax = max(counts)
+        buf = torch.zeros((amax, Cc + 1), device=X.device, dtype=X.dtype)
+        buf[:A, :Cc] = X
+        buf[:A, Cc] = y
+        bufs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(bufs, buf, group=self.group)
+        X_all = torch.cat([b[:c, :Cc] for b, c in zip(bufs, counts)], dim=0).contiguous()
+        y_all = torch.cat([b[:c, Cc] for b, c in zip(bufs, counts)], dim=0).contiguous()
+        return X_all, y_all, sum(counts[:rank])
+
+
+class SegLossReduce:
+    """out = [loss_r, N_r, 1/N_r] -> [sum_r(loss_r N_r) / N_g, N_g, 1/N_g]."""
+
+    def __init__(self, group=None):
+        self.group = group
+
+    def __call__(self, out: torch.Tensor) -> torch.Tensor:
+        t = torch.stack([out[0] * out[1], out[1]])
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        n = t[1]
+        inv = torch.where(n > 0, 1.0 / n.clamp_min(1.0), torch.zeros_like(n))
+        return torch.stack([t[0] * inv, n, inv])
+
+
+class DataParallelStep:
+    """Wraps a ``TrainStep`` (built with ``opts.batch_size`` = GLOBAL batch) for one rank."""
+
+    def __init__(self, ts, rank: int, world: int, group=None):
+        self.ts, self.rank, self.world, self.group = ts, rank, world, group
+        rg = RowGather(group)
+        ts.supcon_criterion.row_gather = rg
+        ts.pixelcontrast_criterion.row_gather = rg
+        red = SegLossReduce(group)
+        ts.criterion.dist_reduce = red
+        ts.ce_criterion.dist_reduce = red
+        self.params: List[torch.nn.Parameter] = [p for p in ts.model.parameters()]
+        # identical initial parameters / buffers on every rank
+        for t in list(ts.model.parameters()) + list(ts.model.buffers()) + list(ts.supcon_criterion.parameters()):
+            dist.broadcast(t.data, src=0, group=group)
+        self._flat = None
+
+    def _allreduce_grads(self):
+        ps = [p for p in self.params if p.grad is not None]
+        n = sum(p.numel() for p in ps)
+        if self._flat is None or self._flat.numel() != n:
+            self._flat = torch.empty(n, device=ps[0].device, dtype=ps[0].dtype)
+        flat, o = self._flat, 0
+        views = []
+        for p in ps:
+            k = p.numel()
+            # same element order as the parameter's own storage (channels_last for conv weights)
+            v = torch.as_strided(flat, p.size(), p.stride(), o)
+            v.copy_(p.grad)
+            views.append(v)
+            o += k
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        for p, v in zip(ps, views):
+            p.grad = v
+
+    def step(self, sample) -> Dict[str, torch.Tensor]:
+        out = self.ts.step(sample, do_optimizer_step=False)
+        self._allreduce_grads()
+        self.ts.optimizer.step()
+        return out

@@ -44,11 +44,14 @@ def global_avg_pool(x: torch.Tensor) -> torch.Tensor:
 # --------------------------------------------------------------------------- #
 class _SegLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logits, target, ldw, cw, mode, gamma, ignore):
+    def forward(ctx, logits, target, ldw, cw, mode, gamma, ignore, reduce_fn=None):
         lg = logits.detach()
         if not lg.is_contiguous():
             lg = lg.contiguous()
         out, grad = ops.seg_loss(lg, target, ldw, cw, mode, gamma, ignore)
+        if reduce_fn is not None:
+            # data parallel: loss = (sum over all ranks) / (count over all ranks); see dcs_amd/dist.py
+            out = reduce_fn(out)
         ctx.grad, ctx.out = grad, out
         return out[0].clone()
 
@@ -59,7 +62,7 @@ class _SegLossFn(torch.autograd.Function):
             raise RuntimeError("seg loss backward called twice")
         ctx.grad = None
         ops.scale_inplace(grad, _scalar(g), ctx.out[2:3])
-        return grad, None, None, None, None, None, None
+        return grad, None, None, None, None, None, None, None
 
 
 class _UpsampleNCHWFn(torch.autograd.Function):
@@ -101,6 +104,7 @@ class BoundaryAwareFocalLoss(nn.Module):
         self.device = device
         self.opts = opts
         self._cw = None
+        self.dist_reduce = None            # set by dcs_amd.dist.DataParallelStep
 
     def _class_weight(self, dev):
         if self.weight is None:
@@ -124,7 +128,7 @@ class BoundaryAwareFocalLoss(nn.Module):
             input = _UpsampleNCHWFn.apply(input, tuple(target.shape[-2:]))
         ldw = batch["label_distance_weight"].to(input.device, input.dtype).contiguous()
         loss = _SegLossFn.apply(input, _prep_target(target), ldw, self._class_weight(input.device), self._mode(),
-                                float(self.gamma), int(self.ignore_id))
+                                float(self.gamma), int(self.ignore_id), self.dist_reduce)
         self.step_counter += 1
         return loss
 
@@ -145,12 +149,14 @@ class SemsegCrossEntropy(nn.Module):
     def __init__(self, num_classes=19, ignore_id=255, print_each=20):
         super().__init__()
         self.num_classes, self.ignore_id, self.step_counter, self.print_each = num_classes, ignore_id, 0, print_each
+        self.dist_reduce = None
 
     def forward(self, logits, labels, **kwargs):
         if logits.shape[-2:] != labels.shape[-2:]:
             logits = _UpsampleNCHWFn.apply(logits, tuple(labels.shape[-2:]))
         self.step_counter += 1
-        return _SegLossFn.apply(logits, _prep_target(labels), None, None, "ce", 0.0, int(self.ignore_id))
+        return _SegLossFn.apply(logits, _prep_target(labels), None, None, "ce", 0.0, int(self.ignore_id),
+                                self.dist_reduce)
 
 
 # --------------------------------------------------------------------------- #
@@ -170,7 +176,7 @@ def _identity_bn(Cc, dev, dtype=torch.float32):
 
 class _SupConFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, labels, w1, b1, w2, b2, temperature):
+    def forward(ctx, features, labels, w1, b1, w2, b2, temperature, row_gather=None):
         v = nhwc(features.detach())
         N, H, W, Cc = v.shape
         pooled = ops.colsum(v.reshape(N * H * W, Cc), B=N, scale=1.0 / (H * W))[:, 0, :].contiguous()
@@ -178,7 +184,12 @@ class _SupConFn(torch.autograd.Function):
         h1 = ops.linear(pooled, w1c, b1.detach().contiguous())
         a1 = ops.bn_act(h1, _identity_bn(h1.shape[1], h1.device, h1.dtype), relu=True)
         f = ops.linear(a1, w2c, b2.detach().contiguous())
-        loss, dF = ops.contrast_fwd_bwd(f, labels, 1, temperature)
+        if row_gather is None:
+            loss, dF = ops.contrast_fwd_bwd(f, labels, 1, temperature)
+        else:                                   # global-batch denominator: every rank evaluates all rows
+            f_all, y_all, start = row_gather(f, labels)
+            loss, dF_all = ops.contrast_fwd_bwd(f_all, y_all, 1, temperature)
+            dF = dF_all[start:start + f.shape[0]].contiguous()
         ctx.saved = (pooled, a1, dF, w1c, w2c, (N, H, W, Cc))
         return loss.reshape(()).clone()
 
@@ -198,7 +209,7 @@ class _SupConFn(torch.autograd.Function):
         dpool = ops.linear(dh1, ops.transpose(w1c))
         gfeat = torch.zeros((N, H, W, Cc), device=dF.device, dtype=dF.dtype)
         ops.add_rowvec_bcast(gfeat, dpool, 1.0 / (H * W))
-        return gfeat.permute(0, 3, 1, 2), None, dw1, db1, dw2, db2, None
+        return gfeat.permute(0, 3, 1, 2), None, dw1, db1, dw2, db2, None, None
 
 
 class SupConLoss(nn.Module):
@@ -218,6 +229,7 @@ class SupConLoss(nn.Module):
         self.projection = nn.Sequential(nn.Linear(dim_in, dim_in), nn.ReLU(inplace=True),
                                         nn.Linear(dim_in, feat_dim)).to(self.device)
         self.contrast_mode = "all"
+        self.row_gather = None             # set by dcs_amd.dist.DataParallelStep
 
     def forward(self, features, class_labels=None, mask=None):
         if features.dim() != 4:
@@ -239,7 +251,7 @@ class SupConLoss(nn.Module):
         if self.temperature != self.base_temperature:
             raise NotImplementedError("temperature != base_temperature")
         return _SupConFn.apply(features, lab2, p[0].weight, p[0].bias, p[2].weight, p[2].bias,
-                               float(self.temperature))
+                               float(self.temperature), self.row_gather)
 
 
 # --------------------------------------------------------------------------- #
@@ -247,11 +259,16 @@ class SupConLoss(nn.Module):
 # --------------------------------------------------------------------------- #
 class _PixelContrastFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, rowidx, y, temperature):
+    def forward(ctx, feats, rowidx, y, temperature, row_gather=None):
         v = nhwc(feats.detach())
         N, H, W, Cc = v.shape
         X = ops.gather_rows(v.reshape(N * H * W, Cc), rowidx)
-        loss, dX = ops.contrast_fwd_bwd(X, y, 0, temperature)
+        if row_gather is None:
+            loss, dX = ops.contrast_fwd_bwd(X, y, 0, temperature)
+        else:
+            X_all, y_all, start = row_gather(X, y)
+            loss, dX_all = ops.contrast_fwd_bwd(X_all, y_all, 0, temperature)
+            dX = dX_all[start:start + X.shape[0]].contiguous()
         ctx.saved = (dX, rowidx, (N, H, W, Cc))
         return loss.reshape(()).clone()
 
@@ -262,7 +279,7 @@ class _PixelContrastFn(torch.autograd.Function):
         ops.scale_inplace(dX, _scalar(g))
         gfeat = torch.zeros((N, H, W, Cc), device=dX.device, dtype=dX.dtype)
         ops.scatter_add_rows(dX, rowidx, gfeat)
-        return gfeat.permute(0, 3, 1, 2), None, None, None
+        return gfeat.permute(0, 3, 1, 2), None, None, None, None
 
 
 def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):
@@ -322,6 +339,7 @@ class PixelContrastLoss(nn.Module, ABC):
         self.loss_weight = 1
         self.contrast_mode = "all"
         self.last_anchors = None          # (img [T], cls [T], pix [T, n_view]) of the last call, for tests
+        self.row_gather = None            # set by dcs_amd.dist.DataParallelStep
 
     def forward(self, feats, labels=None, predict=None):
         B, Cf, h, w = feats.shape
@@ -353,4 +371,4 @@ class PixelContrastLoss(nn.Module, ABC):
         self.last_anchors = (img, cls, pix.view(n_view, T), n_view)
         if self.temperature != self.base_temperature:
             raise NotImplementedError("temperature != base_temperature")
-        return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature))
+        return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature), self.row_gather)

@@ -260,7 +260,8 @@ class SwiftNetEngine:
             if not acc:
                 grads[m.weight] = torch.empty_like(m.weight)
                 grads[m.bias] = torch.empty_like(m.bias)
-            return ops.bn_bwd(g, y, bn, m.weight, dgamma=grads[m.weight], dbeta=grads[m.bias], acc_param=acc, **kw)
+            return ops.bn_bwd(g, y, bn, m.weight, dgamma=grads[m.weight], dbeta=grads[m.bias], acc_param=acc,
+                              training=training, **kw)
 
         tape = saved.tape
         pos = len(tape) - 1
@@ -325,15 +326,17 @@ class SwiftNetEngine:
                 _, blk, x, y1, bn1, z1, y2, bn2, yd, bnd, out = item
                 s = blk.stride
                 dy2, gm = bn_bwd(blk.bn2, g_cur, y2, bn2, masksrc=out, want_gm=True)
-                ops.bn_ema_again(bn2, blk.bn2.running_mean, blk.bn2.running_var, y2.numel() // y2.shape[-1],
-                                 momentum=blk.bn2.momentum)
-                self._nbt.append(blk.bn2)
+                if training:       # activation-checkpoint recompute side effect
+                    ops.bn_ema_again(bn2, blk.bn2.running_mean, blk.bn2.running_var, y2.numel() // y2.shape[-1],
+                                     momentum=blk.bn2.momentum)
+                    self._nbt.append(blk.bn2)
                 wgrad(blk.conv2, z1, dy2, 1, 1)
                 g_z1 = ops.conv_dgrad(dy2, wp(blk.conv2), z1.shape[1:3], 1, 1)
                 dy1, _ = bn_bwd(blk.bn1, g_z1, y1, bn1, relu=True)
-                ops.bn_ema_again(bn1, blk.bn1.running_mean, blk.bn1.running_var, y1.numel() // y1.shape[-1],
-                                 momentum=blk.bn1.momentum)
-                self._nbt.append(blk.bn1)
+                if training:
+                    ops.bn_ema_again(bn1, blk.bn1.running_mean, blk.bn1.running_var, y1.numel() // y1.shape[-1],
+                                     momentum=blk.bn1.momentum)
+                    self._nbt.append(blk.bn1)
                 wgrad(blk.conv1, x, dy1, s, 1)
                 if blk.downsample is not None:
                     dyd, _ = bn_bwd(blk.downsample[1], gm, yd, bnd)

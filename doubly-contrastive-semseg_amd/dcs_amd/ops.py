@@ -307,7 +307,7 @@ def bn_act(y, bn, r=None, bn2=None, relu=True):
 
 
 def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=False, dy_out=None, acc_dy=False,
-           dgamma=None, dbeta=None, acc_param=False):
+           dgamma=None, dbeta=None, acc_param=False, training=True):
     """BatchNorm (+ReLU mask) backward.  Returns (dy, gm).  dgamma/dbeta are written (or accumulated)."""
     _req(g), _req(y)
     Cc = y.shape[-1]
@@ -324,7 +324,7 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
     gm = torch.empty_like(y) if want_gm else None
     _call("dcs_bn_bwd_apply", _p(g), _p(y), _p(masksrc), _p(bn), _p(gamma), _p(sums), _p(dy), _p(gm), _p(dgamma),
           _p(dbeta), rows, Cc, 1 if relu else 0, 1 if (acc_dy and dy_out is not None) else 0, 0,
-          1 if acc_param else 0, _stream())
+          1 if acc_param else 0, 1 if training else 0, _stream())
     return dy, gm
 
 

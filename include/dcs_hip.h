@@ -106,11 +106,12 @@ int dcs_bn_ema_again(const float* bn, float* running_mean, float* running_var, i
 int dcs_bn_act(const float* y, const float* bn, const float* r, const float* bn2, float* z,
                int64_t rows, int C, int relu, void* stream);
 /* BN backward apply: gm = g*mask; dy (+)= gamma*invstd*(gm - s0/cnt - xhat*s1/cnt);
- * optional gm_out (+)= gm.  sums = [2][C] from dcs_colsum_* mode 1.  dgamma/dbeta (+)= s1/s0. */
+ * optional gm_out (+)= gm.  sums = [2][C] from dcs_colsum_* mode 1.  dgamma/dbeta (+)= s1/s0.
+ * training = 0 (eval-mode BN, running statistics): dy = gamma*invstd*gm. */
 int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
                      const float* gamma, const float* sums, float* dy, float* gm_out,
                      float* dgamma, float* dbeta, int64_t rows, int C, int relu, int acc_dy,
-                     int acc_gm, int acc_param, void* stream);
+                     int acc_gm, int acc_param, int training, void* stream);
 
 /* ---- pyramid / pooling / resize -------------------------------------------------------------*/
 /* resnet_pyramid.py:296-314: (x-mean)/std then bicubic 1/2 and 1/4 (A=-0.75, no antialias).

@@ -150,7 +150,7 @@ def bn_act(y, bn, r=None, bn2=None, relu=True):
 
 
 def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=False, dy_out=None, acc_dy=False,
-           dgamma=None, dbeta=None, acc_param=False):
+           dgamma=None, dbeta=None, acc_param=False, training=True):
     C = y.shape[-1]
     rows = y.numel() // C
     gm = g
@@ -168,7 +168,7 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
             dgamma.copy_(s1); dbeta.copy_(s0)
     dy = None
     if want_dy:
-        v = gamma.detach() * bn[3] * (gm - s0 / rows - xhat * (s1 / rows))
+        v = gamma.detach() * bn[3] * ((gm - s0 / rows - xhat * (s1 / rows)) if training else gm)
         if dy_out is not None:
             if acc_dy:
                 dy_out.add_(v)
