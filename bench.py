@@ -109,7 +109,11 @@ class ConvProfiler:
 
 def cpu_baseline(O, args):
     """Oracle train step on the host cores: bounded sample = one labelled image (two crops) of the same size."""
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, avail)))       # the GPU box grants ~16 host cores per GPU
     b = 1
     two = "supcon" in args.criterion
     img, labels, ldw, weather, cw = O.synthetic_batch(b, args.height, args.width, seed=100, two_crops=two, cell=64)
@@ -120,6 +124,7 @@ def cpu_baseline(O, args):
         t0 = time.perf_counter()
         O.train_step(state, proj, opt, img, labels.clone(), ldw, weather, cw, args.criterion, b)
         times.append(time.perf_counter() - t0)
+        print(f"[cpu_baseline] step {it}: {times[-1]:.1f} s on {torch.get_num_threads()} threads", file=sys.stderr, flush=True)
     sec = sum(times[1:]) / max(len(times) - 1, 1)
     return {"value": b / sec, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{args.cpu_steps} timed steps (1 warm-up) of B={b} labelled image ({2 if two else 1} crops) at "
