@@ -25,6 +25,20 @@ constexpr int LDK = 36;   // LDS row stride in floats: 144 B = 9 x 16 B, odd in 
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// Guarded operand loads are buffer loads: a lane whose element is padding / out of range gets the byte offset
+// OOB (>= num_records) and the hardware range check returns 0.  No branch, no select, 32-bit addressing, and
+// hipcc keeps the loads in flight across the MFMA block (a conditional load makes it branch around every load and
+// drain vmcnt per element: cdna_hip_programming.md, trap (c)).
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, long long bytes) {
+  const unsigned n = bytes > 0x7FFFFFFFll ? 0x7FFFFFFFu : (bytes < 0 ? 0u : (unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n, 0x00020000);
+}
+__device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+  return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 template <int BN>
 __global__ __launch_bounds__(256, 2)
@@ -40,6 +54,7 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
   __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
   __shared__ long long rowoff[BM];
+  __shared__ int s_oy[DCS_MAX_TAPS], s_ox[DCS_MAX_TAPS], s_wo[DCS_MAX_TAPS], s_to[DCS_MAX_TAPS];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -66,18 +81,37 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     rowoff[tid] = off;
   }
 
-  int r_n[4], r_y[4], r_x[4];
-  bool r_ok[4];
+  // Source addressing is 32-bit relative to the first image this block touches (a block spans 128 pixels).
+  const int n0 = (int)(m0 / TYX);
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(wgt, (long long)g.Cout * g.wstride * 4);
+
+  if (tid < g.ntaps) {
+    s_oy[tid] = g.offy[tid]; s_ox[tid] = g.offx[tid]; s_wo[tid] = g.wofs[tid];
+    s_to[tid] = (g.offy[tid] * g.SW + g.offx[tid]) * g.src_cstride;
+  }
+
+  int r_base[4], r_y[4], r_x[4];     // element offset of the row's (tap 0,0) source pixel; invalid rows: r_y = -2^20
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const long long m = m0 + lrow + 32 * i;
-    r_ok[i] = m < M;
-    const long long mm = r_ok[i] ? m : 0;
+    const bool ok = m < M;
+    const long long mm = ok ? m : m0;
     const int n = (int)(mm / TYX);
     const int rem = (int)(mm - (long long)n * TYX);
     const int ty = rem / g.TX, tx = rem - ty * g.TX;
-    r_n[i] = n; r_y[i] = ty * g.sy; r_x[i] = tx * g.sx;
+    r_y[i] = ok ? ty * g.sy : -(1 << 20);
+    r_x[i] = tx * g.sx;
+    r_base[i] = (((n - n0) * g.SH + ty * g.sy) * g.SW + tx * g.sx) * g.src_cstride;
   }
+  int b_base[BROWS];                 // element offset of the weight row, or -1 beyond Cout
+#pragma unroll
+  for (int i = 0; i < BROWS; ++i) {
+    const int co = co0 + lrow + 32 * i;
+    b_base[i] = co < g.Cout ? co * g.wstride : -1;
+  }
+  __syncthreads();
 
   const int kch = g.stem ? 1 : (g.K + BK - 1) / BK;
   const int nch = g.ntaps * kch;
@@ -87,36 +121,28 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   auto load_chunk = [&](int ch) {
     const int t = ch / kch;
     const int c0 = (ch - t * kch) * BK;
-    const int oy = g.offy[t], ox = g.offx[t], wo = g.wofs[t];
+    const int oy = s_oy[t], ox = s_ox[t], wo = s_wo[t], to = s_to[t];
     const int kc = c0 + lcol4 * 4;
     if (!g.stem) {
       const bool kvalid = kc < g.K;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int iy = r_y[i] + oy, ix = r_x[i] + ox;
-        const bool ok = r_ok[i] && kvalid && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
-        const long long off = (((long long)r_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
-        ra[i] = ok ? ld4(src + off) : zero4();
+        const bool ok = kvalid && (unsigned)(r_y[i] + oy) < (unsigned)g.SH && (unsigned)(r_x[i] + ox) < (unsigned)g.SW;
+        ra[i] = bld4(rsA, ok ? (unsigned)(r_base[i] + to + kc) * 4u : OOB);
       }
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) {
-        const int co = co0 + lrow + 32 * i;
-        const bool ok = kvalid && co < g.Cout;
-        rb[i] = ok ? ld4(wgt + (long long)co * g.wstride + wo + kc) : zero4();
-      }
+      for (int i = 0; i < BROWS; ++i)
+        rb[i] = bld4(rsB, (kvalid && b_base[i] >= 0) ? (unsigned)(b_base[i] + wo + kc) * 4u : OOB);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int iy = r_y[i] + oy, ix = r_x[i] + ox + lcol4;
-        const bool ok = r_ok[i] && lcol4 < 7 && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
-        const long long off = (((long long)r_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride;
-        ra[i] = ok ? ld4(src + off) : zero4();
+        const bool ok = lcol4 < 7 && (unsigned)(r_y[i] + oy) < (unsigned)g.SH &&
+                        (unsigned)(r_x[i] + ox + lcol4) < (unsigned)g.SW;
+        ra[i] = bld4(rsA, ok ? (unsigned)(r_base[i] + to + lcol4 * 4) * 4u : OOB);
       }
 #pragma unroll
-      for (int i = 0; i < BROWS; ++i) {
-        const int co = co0 + lrow + 32 * i;
-        rb[i] = co < g.Cout ? ld4(wgt + (long long)co * g.wstride + wo + kc) : zero4();
-      }
+      for (int i = 0; i < BROWS; ++i)
+        rb[i] = bld4(rsB, b_base[i] >= 0 ? (unsigned)(b_base[i] + wo + kc) * 4u : OOB);
     }
   };
   auto store_chunk = [&](int buf) {
@@ -242,26 +268,32 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
   float4 rd[NP], rx[NP];
   const int kc = ci0 + lcol4 * 4;
   const int cc = co0 + lcol4 * 4;
+  // 32-bit buffer addressing relative to this split's first dy row / first source image
+  const int n0 = (int)(mbeg / TYX);
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsD = make_rsrc(dy + mbeg * dy_cstride, (mend - mbeg) * (long long)dy_cstride * 4);
+  const bool ccok = cc < g.Cout;
 
   auto load_chunk = [&](long long mc) {
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      const long long m = mc + lrow + RP * i;
-      const bool mok = m < mend;
-      rd[i] = (mok && cc < g.Cout) ? ld4(dy + m * dy_cstride + cc) : zero4();
+      const int mr = (int)(mc - mbeg) + lrow + RP * i;          // rows >= mend - mbeg fall outside rsD -> 0
+      rd[i] = bld4(rsD, ccok ? (unsigned)(mr * dy_cstride + cc) * 4u : OOB);
+      const bool mok = mbeg + mr < mend;
       const int iy = p_ty[i] * g.sy + oy;
       int ix = p_tx[i] * g.sx + ox;
       bool ok = mok && (unsigned)iy < (unsigned)g.SH;
-      long long off;
+      int off;
       if (!g.stem) {
         ok = ok && kc < g.K && (unsigned)ix < (unsigned)g.SW;
-        off = (((long long)p_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
+        off = (((p_n[i] - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
       } else {
         ix += lcol4;
         ok = ok && lcol4 < 7 && (unsigned)ix < (unsigned)g.SW;
-        off = (((long long)p_n[i] * g.SH + iy) * g.SW + ix) * g.src_cstride;
+        off = (((p_n[i] - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride;
       }
-      rx[i] = ok ? ld4(src + off) : zero4();
+      rx[i] = bld4(rsX, ok ? (unsigned)off * 4u : OOB);
       // advance this slot by 32 pixels
       p_tx[i] += 32;
       while (p_tx[i] >= g.TX) { p_tx[i] -= g.TX; p_ty[i] += 1; }
@@ -438,6 +470,9 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
   const long long M = (long long)geom->N * geom->TY * geom->TX;
   long long mps = (M + nsplit - 1) / nsplit;
   mps = (mps + 31) / 32 * 32;
+  // 32-bit buffer offsets inside one split: dy rows and the source pixels they gather from must span < 2 GiB
+  const long long span_src = (mps * geom->sy * geom->sx + 4ll * geom->SW) * geom->src_cstride * 4;
+  if (mps * (long long)dy_cstride * 4 >= 0x7FFFFFFFll || span_src >= 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
   const int keff = geom->stem ? 32 : geom->K;
   const int bt = (geom->Cout > 64 && keff > 64) ? 128 : 64;
   const int coT = (geom->Cout + bt - 1) / bt, ciT = (keff + bt - 1) / bt;
