@@ -40,7 +40,7 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BN>
+template <int BN, bool STEM>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                         const float* __restrict__ bias, float* __restrict__ dst,
@@ -65,16 +65,16 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = bid % ntiles, mtile = bid / ntiles;
   const int co0 = ntile * BN;
-  const long long m0 = (long long)mtile * BM;
-  const long long TYX = (long long)g.TY * g.TX;
-  const long long M = (long long)g.N * TYX;
+  const unsigned m0 = (unsigned)mtile * BM;
+  const unsigned TYX = (unsigned)g.TY * (unsigned)g.TX;
+  const unsigned M = (unsigned)g.N * TYX;
 
   if (tid < BM) {
-    const long long m = m0 + tid;
+    const unsigned m = m0 + tid;
     long long off = -1;
     if (m < M) {
       const int n = (int)(m / TYX);
-      const int rem = (int)(m - (long long)n * TYX);
+      const int rem = (int)(m - (unsigned)n * TYX);
       const int ty = rem / g.TX, tx = rem - ty * g.TX;
       off = (((long long)n * g.DH + (ty * g.dsy + g.dy0)) * g.DW + (tx * g.dsx + g.dx0)) * g.dst_cstride;
     }
@@ -95,11 +95,11 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   int r_base[4], r_y[4], r_x[4];     // element offset of the row's (tap 0,0) source pixel; invalid rows: r_y = -2^20
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const long long m = m0 + lrow + 32 * i;
+    const unsigned m = m0 + lrow + 32 * i;
     const bool ok = m < M;
-    const long long mm = ok ? m : m0;
+    const unsigned mm = ok ? m : m0;
     const int n = (int)(mm / TYX);
-    const int rem = (int)(mm - (long long)n * TYX);
+    const int rem = (int)(mm - (unsigned)n * TYX);
     const int ty = rem / g.TX, tx = rem - ty * g.TX;
     r_y[i] = ok ? ty * g.sy : -(1 << 20);
     r_x[i] = tx * g.sx;
@@ -113,45 +113,42 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   }
   __syncthreads();
 
-  const int kch = g.stem ? 1 : (g.K + BK - 1) / BK;
+  const int kch = STEM ? 1 : (g.K + BK - 1) / BK;
   const int nch = g.ntaps * kch;
 
-  float4 ra[4], rb[BROWS];
+  // Register staging slots: 0..3 = the four A rows of this thread, 4.. = its B rows.
+  constexpr int NSLOT = 4 + BROWS;
+  float4 rs[NSLOT];
 
-  auto load_chunk = [&](int ch) {
+  // chunk -> (tap, channel offset); per-chunk scalars are refreshed once per chunk by set_chunk()
+  int c_oy = 0, c_ox = 0, c_wo = 0, c_to = 0, c_kc = 0;
+  bool c_kvalid = true;
+  auto set_chunk = [&](int ch) {
     const int t = ch / kch;
     const int c0 = (ch - t * kch) * BK;
-    const int oy = s_oy[t], ox = s_ox[t], wo = s_wo[t], to = s_to[t];
-    const int kc = c0 + lcol4 * 4;
-    if (!g.stem) {
-      const bool kvalid = kc < g.K;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = kvalid && (unsigned)(r_y[i] + oy) < (unsigned)g.SH && (unsigned)(r_x[i] + ox) < (unsigned)g.SW;
-        ra[i] = bld4(rsA, ok ? (unsigned)(r_base[i] + to + kc) * 4u : OOB);
+    c_oy = s_oy[t]; c_ox = s_ox[t]; c_wo = s_wo[t]; c_to = s_to[t];
+    c_kc = c0 + lcol4 * 4;
+    c_kvalid = STEM ? true : c_kc < g.K;
+  };
+  auto load_slot = [&](int sl) {
+    if (sl < 4) {
+      const int i = sl;
+      if (!STEM) {
+        const bool ok = c_kvalid && (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH && (unsigned)(r_x[i] + c_ox) < (unsigned)g.SW;
+        rs[sl] = bld4(rsA, ok ? (unsigned)(r_base[i] + c_to + c_kc) * 4u : OOB);
+      } else {
+        const bool ok = lcol4 < 7 && (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH &&
+                        (unsigned)(r_x[i] + c_ox + lcol4) < (unsigned)g.SW;
+        rs[sl] = bld4(rsA, ok ? (unsigned)(r_base[i] + c_to + lcol4 * 4) * 4u : OOB);
       }
-#pragma unroll
-      for (int i = 0; i < BROWS; ++i)
-        rb[i] = bld4(rsB, (kvalid && b_base[i] >= 0) ? (unsigned)(b_base[i] + wo + kc) * 4u : OOB);
     } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const bool ok = lcol4 < 7 && (unsigned)(r_y[i] + oy) < (unsigned)g.SH &&
-                        (unsigned)(r_x[i] + ox + lcol4) < (unsigned)g.SW;
-        ra[i] = bld4(rsA, ok ? (unsigned)(r_base[i] + to + lcol4 * 4) * 4u : OOB);
-      }
-#pragma unroll
-      for (int i = 0; i < BROWS; ++i)
-        rb[i] = bld4(rsB, b_base[i] >= 0 ? (unsigned)(b_base[i] + wo + kc) * 4u : OOB);
+      const int i = sl - 4;
+      rs[sl] = bld4(rsB, (c_kvalid && b_base[i] >= 0) ? (unsigned)(b_base[i] + c_wo + c_kc) * 4u : OOB);
     }
   };
-  auto store_chunk = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * i) * LDK + lcol4 * 4]) = ra[i];
-#pragma unroll
-    for (int i = 0; i < BROWS; ++i)
-      *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * i) * LDK + lcol4 * 4]) = rb[i];
+  auto store_slot = [&](int sl, int buf) {
+    if (sl < 4) *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * sl) * LDK + lcol4 * 4]) = rs[sl];
+    else        *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * (sl - 4)) * LDK + lcol4 * 4]) = rs[sl];
   };
 
   f32x16 acc[TM][TN];
@@ -162,38 +159,63 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  load_chunk(0);
-  store_chunk(0);
+  // Software pipeline (register-staged, write-after-barrier): registers hold chunk ch+1 while chunk ch is
+  // computed.  After the first MFMA group of iteration ch each slot is written to the other LDS buffer (last read
+  // in iteration ch-1, before the barrier) and immediately re-loaded with chunk ch+2, one slot per pair of MFMAs,
+  // so LDS writes, address arithmetic and load issue sit in the shadow of the matrix pipe and every global load
+  // has a full iteration (>= 48 MFMAs per wave) to land.  The tail iterations re-load the last chunk (harmless).
+  set_chunk(0);
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, 0);
+  set_chunk(nch > 1 ? 1 : 0);
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
   __syncthreads();
+
+  constexpr int G = TM * TN * 4;               // MFMAs per k8 group
+  float av[2][TM][4], bv[2][TN][4];
+  auto frag_load = [&](int set, const float* Ab, const float* Bb, int kk) {
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const float4 v = ld4(Ab + a * 32 * LDK + kk);
+      av[set][a][0] = v.x; av[set][a][1] = v.y; av[set][a][2] = v.z; av[set][a][3] = v.w;
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const float4 v = ld4(Bb + b * 32 * LDK + kk);
+      bv[set][b][0] = v.x; bv[set][b][1] = v.y; bv[set][b][2] = v.z; bv[set][b][3] = v.w;
+    }
+  };
+  auto mfma_range = [&](int set, int lo, int hi) {     // MFMAs lo..hi-1 of a group, order j, a, b
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      if (q < lo || q >= hi) continue;
+      const int j = q / (TM * TN), a = (q / TN) % TM, b = q % TN;
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[set][a][j], bv[set][b][j], acc[a][b], 0, 0, 0);
+    }
+  };
 
   for (int ch = 0; ch < nch; ++ch) {
     const int buf = ch & 1;
-    const bool more = ch + 1 < nch;
-    if (more) load_chunk(ch + 1);
     const float* Ab = &As[buf][(wm * TM * 32 + l31) * LDK + 4 * h];
     const float* Bb = &Bs[buf][(wn * TN * 32 + l31) * LDK + 4 * h];
+    frag_load(0, Ab, Bb, 0);
+    frag_load(1, Ab, Bb, 8);
+    mfma_range(0, 0, G);
+    set_chunk(ch + 2 < nch ? ch + 2 : nch - 1);
+    frag_load(0, Ab, Bb, 16);
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 8) {
-      float av[TM][4], bv[TN][4];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const float4 v = ld4(Ab + a * 32 * LDK + kk);
-        av[a][0] = v.x; av[a][1] = v.y; av[a][2] = v.z; av[a][3] = v.w;
-      }
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const float4 v = ld4(Bb + b * 32 * LDK + kk);
-        bv[b][0] = v.x; bv[b][1] = v.y; bv[b][2] = v.z; bv[b][3] = v.w;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a][j], bv[b][j], acc[a][b], 0, 0, 0);
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      store_slot(sl, buf ^ 1);
+      load_slot(sl);
+      mfma_range(1, sl * G / NSLOT, (sl + 1) * G / NSLOT);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (more) store_chunk(buf ^ 1);
+    frag_load(1, Ab, Bb, 24);
+    mfma_range(0, 0, G);
+    mfma_range(1, 0, G);
     __syncthreads();
   }
 
@@ -440,21 +462,28 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   DCS_CHECK_ARG(src && wgt && dst && dcs_aligned16(src) && dcs_aligned16(wgt));
   DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout);
   const long long M = (long long)geom->N * geom->TY * geom->TX;
+  DCS_CHECK_ARG(M < 0x7FFFFF00ll);
   const long long mtiles = (M + BM - 1) / BM;
   const int bn = geom->Cout > 64 ? 128 : (geom->Cout > 32 ? 64 : 32);
   const int ntiles = (geom->Cout + bn - 1) / bn;
   const long long blocks = mtiles * ntiles;
   DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
   hipStream_t s = dcs_stream(stream);
+#define LAUNCH_GATHER(B)                                                                                              \
+  do {                                                                                                                \
+    if (geom->stem)                                                                                                   \
+      hipLaunchKernelGGL((conv_gather_kernel<B, true>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, \
+                         *geom, accumulate, ntiles);                                                                  \
+    else                                                                                                              \
+      hipLaunchKernelGGL((conv_gather_kernel<B, false>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias,     \
+                         dst, *geom, accumulate, ntiles);                                                             \
+  } while (0)
   if (bn == 128)
-    hipLaunchKernelGGL(conv_gather_kernel<128>, dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, *geom,
-                       accumulate, ntiles);
+    LAUNCH_GATHER(128);
   else if (bn == 64)
-    hipLaunchKernelGGL(conv_gather_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, *geom,
-                       accumulate, ntiles);
+    LAUNCH_GATHER(64);
   else
-    hipLaunchKernelGGL(conv_gather_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, *geom,
-                       accumulate, ntiles);
+    LAUNCH_GATHER(32);
   DCS_LAUNCH_RET();
 }
 
