@@ -386,6 +386,155 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient of 3x3 / stride 1 / pad 1 convolutions, ALL NINE TAPS per block.
+// Block = one 64(co) x 64(ci) tile and one pixel range; a chunk is 32 consecutive output pixels of one image
+// row (requires TX % 32 == 0).  Per chunk the block stages dy[32][64] once and the 3 x 34 pixel input halo
+// x[3][34][64] once and feeds 9 taps x 16 MFMAs per wave from them (tap (r,s), pixel p reads halo row r,
+// column p + s): 34 KB staged per 144 MFMAs per wave, a 4x better ratio than the per-tap kernel.
+// Same write-after-barrier register pipeline as conv_gather_kernel.
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad3x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                          const DcsConvGeom g, const int dy_cstride, const int split0, const int cps /*chunks per split*/,
+                          const int ciT) {
+  constexpr int HW_ = 34;                 // halo width in pixels
+  constexpr int XROWS = 3 * HW_;          // 102 staged input rows
+  constexpr int NSD = 2, NSX = 7, NSLOT = NSD + NSX;
+  __shared__ __attribute__((aligned(16))) float Ds[2][32 * 64];
+  __shared__ __attribute__((aligned(16))) float Xs[2][XROWS * 64];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lcol4 = tid & 15, lrow = tid >> 4;          // 16 float4 per 64-channel row
+
+  const int ciTile = blockIdx.x % ciT, coTile = blockIdx.x / ciT;
+  const int co0 = coTile * 64, ci0 = ciTile * 64;
+  const int split = blockIdx.y;
+  const int cpr = g.TX >> 5;                            // chunks per image row
+  const int nchunks_total = g.N * g.TY * cpr;
+  const int cbeg = split * cps;
+  const int cend = cbeg + cps < nchunks_total ? cbeg + cps : nchunks_total;
+  const int nch = cend > cbeg ? cend - cbeg : 0;
+
+  // chunk coordinates (uniform), advanced incrementally
+  int q_n, q_ty, q_tx;                                  // coordinates of the NEXT chunk to be loaded
+  {
+    const int c = cbeg < nchunks_total ? cbeg : 0;
+    const int per_img = g.TY * cpr;
+    q_n = c / per_img;
+    const int rem = c - q_n * per_img;
+    q_ty = rem / cpr;
+    q_tx = (rem - q_ty * cpr) << 5;
+  }
+  const int n0 = q_n;
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
+  const long long mbeg = (long long)cbeg * 32;
+  const __amdgpu_buffer_rsrc_t rsD = make_rsrc(dy + mbeg * dy_cstride, (long long)nch * 32 * dy_cstride * 4);
+  const int kc = ci0 + lcol4 * 4, cc = co0 + lcol4 * 4;
+  const bool kok = kc < g.K, ccok = cc < g.Cout;
+
+  // per-slot constants of the halo rows this thread stages
+  int xs_hr[NSX], xs_hx[NSX];
+  bool xs_ok[NSX];
+#pragma unroll
+  for (int k = 0; k < NSX; ++k) {
+    const int e = tid + 256 * k;
+    const int row = e >> 4;
+    xs_ok[k] = row < XROWS;
+    xs_hr[k] = row / HW_;
+    xs_hx[k] = row - xs_hr[k] * HW_;
+  }
+
+  float4 rs[NSLOT];
+  int l_chunk = 0;                                      // index (relative to cbeg) of the chunk being loaded
+  auto load_slot = [&](int sl) {
+    if (sl < NSD) {
+      const int mr = l_chunk * 32 + lrow + 16 * sl;     // rows beyond the split fall outside rsD -> 0
+      rs[sl] = bld4(rsD, ccok ? (unsigned)(mr * dy_cstride + cc) * 4u : OOB);
+    } else {
+      const int k = sl - NSD;
+      const int iy = q_ty + xs_hr[k] - 1, ix = q_tx + xs_hx[k] - 1;
+      const bool ok = xs_ok[k] && kok && l_chunk < nch && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+      const int off = (((q_n - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
+      rs[sl] = bld4(rsX, ok ? (unsigned)off * 4u : OOB);
+    }
+  };
+  auto advance_chunk = [&]() {
+    l_chunk += 1;
+    q_tx += 32;
+    if (q_tx >= g.TX) { q_tx = 0; q_ty += 1; }
+    if (q_ty >= g.TY) { q_ty = 0; q_n += 1; }
+  };
+  auto store_slot = [&](int sl, int buf) {
+    if (sl < NSD) {
+      *reinterpret_cast<float4*>(&Ds[buf][(lrow + 16 * sl) * 64 + lcol4 * 4]) = rs[sl];
+    } else {
+      const int k = sl - NSD;
+      if (xs_ok[k]) *reinterpret_cast<float4*>(&Xs[buf][(tid + 256 * k) * 4]) = rs[sl];
+    }
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  advance_chunk();
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, 0);
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  advance_chunk();
+  __syncthreads();
+
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    const float* Db = &Ds[buf][wm * 32 + l31];
+    const float* Xb = &Xs[buf][wn * 32 + l31];
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 8) {
+      float av[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) av[j] = Db[(kk + 4 * h + j) * 64];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int r = t / 3, sx = t % 3;
+        float bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = Xb[(r * HW_ + kk + 4 * h + j + sx) * 64];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[t], 0, 0, 0);
+        if (kk == 0) {               // stage chunk ch+1 into the other buffer and refill the registers with chunk ch+2
+          store_slot(t, buf ^ 1);
+          load_slot(t);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (kk == 0) advance_chunk();
+    }
+    __syncthreads();
+  }
+
+  float* out = slab + (long long)(split0 + split) * g.Cout * g.wstride;
+  const int ci = ci0 + wn * 32 + l31;
+  if (ci < g.K) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < g.Cout) out[(long long)co * g.wstride + t * g.K + ci] = acc[t][r];
+      }
+  }
+}
+
 __global__ void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n,
                                    int nsplit, int accumulate) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -434,6 +583,14 @@ __global__ void transpose_kernel(const float* __restrict__ in, float* __restrict
     const int c = bx + j, r = by + threadIdx.x;
     if (r < R && c < C) out[(long long)c * R + r] = tile[threadIdx.x][j];
   }
+}
+
+// 3x3 / stride 1 / pad 1 forward geometry whose rows split into whole 32-pixel chunks
+bool wgrad3x3_eligible(const DcsConvGeom* g) {
+  if (g->stem || g->ntaps != 9 || g->sy != 1 || g->sx != 1 || (g->TX & 31) != 0 || g->wstride != 9 * g->K) return false;
+  for (int t = 0; t < 9; ++t)
+    if (g->offy[t] != t / 3 - 1 || g->offx[t] != t % 3 - 1 || g->wofs[t] != t * g->K) return false;
+  return g->SH == g->TY && g->SW == g->TX;
 }
 
 int check_geom(const DcsConvGeom* g) {
@@ -502,6 +659,18 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
   // 32-bit buffer offsets inside one split: dy rows and the source pixels they gather from must span < 2 GiB
   const long long span_src = (mps * geom->sy * geom->sx + 4ll * geom->SW) * geom->src_cstride * 4;
   if (mps * (long long)dy_cstride * 4 >= 0x7FFFFFFFll || span_src >= 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
+  if (wgrad3x3_eligible(geom)) {
+    const int cpr = geom->TX / 32;
+    const long long nchunks = (long long)geom->N * geom->TY * cpr;
+    const int cps = (int)((nchunks + nsplit - 1) / nsplit);
+    const int coT = (geom->Cout + 63) / 64, ciT = (geom->K + 63) / 64;
+    const long long span = ((long long)cps * 32 + 4ll * geom->SW) * geom->src_cstride * 4;
+    if ((long long)cps * 32 * dy_cstride * 4 < 0x7FFFFFFFll && span < 0x7FFFFFFFll) {
+      hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0,
+                         dcs_stream(stream), src, dy, slab, *geom, dy_cstride, split0, cps, ciT);
+      DCS_LAUNCH_RET();
+    }
+  }
   const int keff = geom->stem ? 32 : geom->K;
   const int bt = (geom->Cout > 64 && keff > 64) ? 128 : 64;
   const int coT = (geom->Cout + bt - 1) / bt, ciT = (keff + bt - 1) / bt;

@@ -194,9 +194,13 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate):
     Cout, _, R, S = dw.shape
     g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad)
     M = N * g.DH * g.DW
-    bt = 128 if (Cout > 64 and Cin > 64) else 64
-    tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
-    ns = _nsplit(tiles, M)
+    if R == 3 and S == 3 and stride == 1 and pad == 1 and W % 32 == 0:
+        tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
+        ns = max(1, min(-(-1024 // tiles), M // 32))
+    else:
+        bt = 128 if (Cout > 64 and Cin > 64) else 64
+        tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
+        ns = _nsplit(tiles, M)
     n = Cout * R * S * Cin
     slab = torch.empty((ns, n), device=x.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())

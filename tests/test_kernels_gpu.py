@@ -51,6 +51,10 @@ CONV_CASES = [
     (3, 6, 10, 512, 128, 1, 1),
     (1, 33, 17, 128, 128, 3, 1),
     (1, 1, 2, 512, 512, 3, 1),
+    (2, 6, 64, 64, 64, 3, 1),        # W % 32 == 0: nine-tap weight-gradient kernel
+    (1, 5, 32, 128, 64, 3, 1),
+    (3, 3, 96, 64, 128, 3, 1),
+    (1, 2, 32, 256, 256, 3, 1),
 ]
 
 
