@@ -535,13 +535,189 @@ void conv_wgrad3x3_kernel(const float* __restrict__ src, const float* __restrict
   }
 }
 
-__global__ void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n,
-                                   int nsplit, int accumulate) {
-  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = accumulate ? dw[i] : 0.f;
-  for (int k = 0; k < nsplit; ++k) s += slab[(long long)k * n + i];
-  dw[i] = s;
+// ------------------------------------------------------------------------------------------------
+// weight gradient of the 7x7 / stride 2 / pad 3 stem on the NHWC4 image, all seven filter rows per block.
+// A chunk is 32 consecutive output pixels of one output row (requires TX % 32 == 0).  Per chunk the block stages
+// dy[32][64] and the 7 x 69 pixel input patch (rows 2*oy-3 .. 2*oy+3, columns 2*ox0-3 .. 2*ox0+65) once.  The
+// im2col row of pixel p for filter row r is the contiguous run patch[r][8p .. 8p+31] (7 px x 4 ch + one pad px
+// whose products land in the padded weight slots and are dropped by the unpack), so no im2col copy exists.
+// Wave w owns filter rows 2w, 2w+1 (row 7 is a dummy) x both 32-channel output tiles.
+__global__ __launch_bounds__(256, 2)
+void stem_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                       const DcsConvGeom g, const int dy_cstride, const int split0, const int cps) {
+  constexpr int PW = 69;                    // patch width in pixels
+  constexpr int PROW = PW * 4 + 4;          // floats per patch row (+4 pad floats so 8p+31 stays in the row)
+  constexpr int NSLOT = 4;                  // 2 dy + 2 patch float4 per thread
+  __shared__ __attribute__((aligned(16))) float Ds[2][32 * 64];
+  __shared__ __attribute__((aligned(16))) float Ps[2][7 * PROW];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int lcol4 = tid & 15, lrow = tid >> 4;
+  const int split = blockIdx.x;
+  const int cpr = g.TX >> 5;
+  const int nchunks_total = g.N * g.TY * cpr;
+  const int cbeg = split * cps;
+  const int cend = cbeg + cps < nchunks_total ? cbeg + cps : nchunks_total;
+  const int nch = cend > cbeg ? cend - cbeg : 0;
+
+  int q_n, q_ty, q_tx;
+  {
+    const int c = cbeg < nchunks_total ? cbeg : 0;
+    const int per_img = g.TY * cpr;
+    q_n = c / per_img;
+    const int rem = c - q_n * per_img;
+    q_ty = rem / cpr;
+    q_tx = (rem - q_ty * cpr) << 5;
+  }
+  const int n0 = q_n;
+  const long long img_elems = (long long)g.SH * g.SW * 4;
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
+  const long long mbeg = (long long)cbeg * 32;
+  const __amdgpu_buffer_rsrc_t rsD = make_rsrc(dy + mbeg * dy_cstride, (long long)nch * 32 * dy_cstride * 4);
+
+  // patch staging: element e = tid + 256*k < 7*69 -> (row, pixel)
+  int ps_r[2], ps_c[2];
+  bool ps_ok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    ps_ok[k] = e < 7 * PW;
+    ps_r[k] = e / PW;
+    ps_c[k] = e - ps_r[k] * PW;
+  }
+
+  float4 rs[NSLOT];
+  int l_chunk = 0;
+  auto load_slot = [&](int sl) {
+    if (sl < 2) {
+      const int mr = l_chunk * 32 + lrow + 16 * sl;
+      rs[sl] = bld4(rsD, (unsigned)(mr * dy_cstride + lcol4 * 4) * 4u);
+    } else {
+      const int k = sl - 2;
+      const int iy = 2 * q_ty - 3 + ps_r[k], ix = 2 * q_tx - 3 + ps_c[k];
+      const bool ok = ps_ok[k] && l_chunk < nch && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+      rs[sl] = bld4(rsX, ok ? (unsigned)((((q_n - n0) * g.SH + iy) * g.SW + ix) * 4) * 4u : OOB);
+    }
+  };
+  auto advance_chunk = [&]() {
+    l_chunk += 1;
+    q_tx += 32;
+    if (q_tx >= g.TX) { q_tx = 0; q_ty += 1; }
+    if (q_ty >= g.TY) { q_ty = 0; q_n += 1; }
+  };
+  auto store_slot = [&](int sl, int buf) {
+    if (sl < 2) {
+      *reinterpret_cast<float4*>(&Ds[buf][(lrow + 16 * sl) * 64 + lcol4 * 4]) = rs[sl];
+    } else {
+      const int k = sl - 2;
+      if (ps_ok[k]) *reinterpret_cast<float4*>(&Ps[buf][ps_r[k] * PROW + ps_c[k] * 4]) = rs[sl];
+    }
+  };
+
+  if (tid < 14) {                           // the pad floats at the end of each patch row are read, keep them zero
+    const int b = tid / 7, r = tid % 7;
+    *reinterpret_cast<float4*>(&Ps[b][r * PROW + PW * 4]) = zero4();
+  }
+
+  f32x16 acc[2][2];                         // [filter row 2w + a][output-channel tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  advance_chunk();
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, 0);
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  advance_chunk();
+  __syncthreads();
+
+  const int r0 = 2 * wid;
+  const bool two = r0 + 1 < 7;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    const float* Db = &Ds[buf][l31];
+    const float* P0 = &Ps[buf][r0 * PROW + l31];
+    const float* P1 = &Ps[buf][(two ? r0 + 1 : r0) * PROW + l31];
+#pragma unroll
+    for (int kk = 0; kk < 32; kk += 8) {
+      float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int pix = kk + 4 * h + j;
+        a0[j] = Db[pix * 64];
+        a1[j] = Db[pix * 64 + 32];
+        b0[j] = P0[8 * pix];
+        b1[j] = P1[8 * pix];
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b0[j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b0[j], acc[0][1], 0, 0, 0);
+        if (two) {
+          acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[j], b1[j], acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[j], b1[j], acc[1][1], 0, 0, 0);
+        }
+        if (kk == 0) {
+          store_slot(j, buf ^ 1);
+          load_slot(j);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      if (kk == 0) advance_chunk();
+    }
+    __syncthreads();
+  }
+
+  float* out = slab + (long long)(split0 + split) * g.Cout * g.wstride;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int r = r0 + a;
+    if (r >= 7) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = b * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        out[(long long)co * g.wstride + r * 32 + l31] = acc[a][b][q];
+      }
+  }
+}
+
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i].  Block = 64 columns x 4 split lanes: each lane sums splits
+// sl, sl+4, ... with independent loads in flight, then the 4 partial sums are added in fixed order (deterministic).
+__global__ __launch_bounds__(256)
+void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nsplit,
+                        int accumulate) {
+  __shared__ float sm[4][64];
+  const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + c;
+  float s = 0.f;
+  if (i < n) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = sl;
+    for (; k + 12 < nsplit; k += 16) {
+      s0 += slab[(long long)k * n + i];
+      s1 += slab[(long long)(k + 4) * n + i];
+      s2 += slab[(long long)(k + 8) * n + i];
+      s3 += slab[(long long)(k + 12) * n + i];
+    }
+    for (; k < nsplit; k += 4) s0 += slab[(long long)k * n + i];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  sm[sl][c] = s;
+  __syncthreads();
+  if (sl == 0 && i < n) {
+    const float t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
+    dw[i] = (accumulate ? dw[i] : 0.f) + t;
+  }
 }
 
 __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int Cout, int RS,
@@ -659,6 +835,16 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
   // 32-bit buffer offsets inside one split: dy rows and the source pixels they gather from must span < 2 GiB
   const long long span_src = (mps * geom->sy * geom->sx + 4ll * geom->SW) * geom->src_cstride * 4;
   if (mps * (long long)dy_cstride * 4 >= 0x7FFFFFFFll || span_src >= 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
+  if (geom->stem && (geom->TX & 31) == 0 && geom->Cout == 64 && geom->wstride == 224 && dy_cstride == 64) {
+    const long long nchunks = (long long)geom->N * geom->TY * (geom->TX / 32);
+    const int cps = (int)((nchunks + nsplit - 1) / nsplit);
+    const long long span = ((long long)cps * 64 + 8ll * geom->SW) * 16;
+    if ((long long)cps * 32 * dy_cstride * 4 < 0x7FFFFFFFll && span < 0x7FFFFFFFll) {
+      hipLaunchKernelGGL(stem_wgrad_kernel, dim3((unsigned)nsplit), dim3(256), 0, dcs_stream(stream), src, dy, slab, *geom,
+                         dy_cstride, split0, cps);
+      DCS_LAUNCH_RET();
+    }
+  }
   if (wgrad3x3_eligible(geom)) {
     const int cpr = geom->TX / 32;
     const long long nchunks = (long long)geom->N * geom->TY * cpr;
@@ -685,7 +871,7 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
 
 extern "C" int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, void* stream) {
   DCS_CHECK_ARG(slab && dw && n > 0 && nsplit > 0);
-  hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dcs_stream(stream), slab, dw,
+  hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, dcs_stream(stream), slab, dw,
                      (long long)n, nsplit, accumulate);
   DCS_LAUNCH_RET();
 }

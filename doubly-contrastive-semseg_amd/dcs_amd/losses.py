@@ -341,7 +341,9 @@ class PixelContrastLoss(nn.Module, ABC):
         self.last_anchors = None          # (img [T], cls [T], pix [T, n_view]) of the last call, for tests
         self.row_gather = None            # set by dcs_amd.dist.DataParallelStep
 
-    def forward(self, feats, labels=None, predict=None):
+    def _count(self, feats, labels, predict):
+        """Device half of the sampler (argmax, nearest label downsample, per-class hard/easy histogram) and the
+        asynchronous D2H copy of the [B, C, 2] counts."""
         B, Cf, h, w = feats.shape
         nc = predict.shape[1]
         assert predict.shape[-1] == feats.shape[-1], "{} {}".format(predict.shape, feats.shape)
@@ -354,7 +356,31 @@ class PixelContrastLoss(nn.Module, ABC):
         if lab.dtype != torch.int64 or not lab.is_contiguous():
             lab = lab.long().contiguous()
         key, hist = ops.anchor_keys_raw(pl, B, h, w, cs, nc, lab, self.ignore_label)
-        counts = hist.sum(1).view(B, nc, 2).cpu()                 # one D2H sync per step (reference: ~3 per class)
+        counts_dev = hist.sum(1).view(B, nc, 2)
+        if counts_dev.is_cuda:
+            counts = torch.empty(counts_dev.shape, dtype=counts_dev.dtype, pin_memory=True)
+            counts.copy_(counts_dev, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+        else:
+            counts, ev = counts_dev, None
+        return dict(key=key, hist=hist, counts=counts, event=ev, labels_ptr=labels.data_ptr(), nc=nc)
+
+    def prefetch(self, feats, labels, predict):
+        """Optional: launch the counting kernel early (must see the labels BEFORE the focal loss rewrites 255 -> 0,
+        trainer.py:151-156).  ``forward`` picks the result up if it is called with the same labels tensor."""
+        self._pre = self._count(feats, labels, predict)
+
+    def forward(self, feats, labels=None, predict=None):
+        B, Cf, h, w = feats.shape
+        pre = getattr(self, "_pre", None)
+        self._pre = None
+        if pre is None or pre["labels_ptr"] != labels.data_ptr():
+            pre = self._count(feats, labels, predict)
+        key, hist, nc = pre["key"], pre["hist"], pre["nc"]
+        if pre["event"] is not None:
+            pre["event"].synchronize()                        # one host wait per step (reference: ~3 per class)
+        counts = pre["counts"]
         plan = plan_anchor_requests(counts, nc, self.max_samples, self.max_views)
         if plan is None:
             raise AttributeError("'NoneType' object has no attribute 'shape'")   # loss.py:341 on (None, None)

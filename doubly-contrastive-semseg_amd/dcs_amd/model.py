@@ -165,8 +165,11 @@ class SwiftNetEngine:
         self._std = fe.img_std.reshape(3).contiguous()
         self._nbt = []
         tape: List[tuple] = [] if need_grad else None
-        Bm, _, H, W = img.shape
-        pyr = ops.normalize_pyramid(img if img.is_floating_point() else img.float(), self._mean, self._std)
+        parts = list(img) if isinstance(img, (list, tuple)) else [img]
+        parts = [t if t.is_floating_point() else t.float() for t in parts]
+        Bm = sum(t.shape[0] for t in parts)
+        H, W = parts[0].shape[2:]
+        pyr = ops.normalize_pyramid(parts if len(parts) > 1 else parts[0], self._mean, self._std)
         wst = ops.pack_stem_weight(fe.conv1.weight)
         skips: List[List[torch.Tensor]] = [[] for _ in range(6)]
         for idx, p in enumerate(pyr):
@@ -365,23 +368,40 @@ class SwiftNetEngine:
 
 
 class _SwiftNetFn(torch.autograd.Function):
+    """Outputs: seg (NCHW), before (NHWC, channel stride 20), fine_feat (NHWC), fine_feat0 (= fine_feat[:B], a
+    view that is its own autograd output: the pixel-contrast gradient then arrives separately instead of going
+    through autograd's split-backward (a 2 GB cat + add per step at C3))."""
+
     @staticmethod
     def forward(ctx, engine: SwiftNetEngine, img, training, supcon, grad_enabled, *params):
         need_grad = grad_enabled and any(p.requires_grad for p in params)
         ctx.set_materialize_grads(False)
         seg, before, ff, saved = engine.forward(img, training, supcon, need_grad)
         ctx.engine, ctx.saved, ctx.params = engine, saved, params
-        outs = [t if t is not None else img.new_zeros(1) for t in (seg, before, ff)]
-        ctx.has = [t is not None for t in (seg, before, ff)]
-        ctx.mark_non_differentiable(*[o for o, h in zip(outs, ctx.has) if not h])
+        B = ff.shape[0] // 2 if supcon else ff.shape[0]
+        ff0 = ff[:B] if supcon else ff.view(ff.shape)
+        outs = [t if t is not None else ff.new_zeros(1) for t in (seg, before)] + [ff, ff0]
+        ctx.has = [seg is not None, before is not None]
+        ctx.mark_non_differentiable(*[o for o, h in zip(outs[:2], ctx.has) if not h])
         return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g_seg, g_before, g_ff):
+    def backward(ctx, g_seg, g_before, g_ff, g_ff0):
         if ctx.saved is None:
             raise RuntimeError("SwiftNet backward without a recorded forward")
+        # both gradient buffers are consumed in place: they are freshly produced by the loss nodes
         if g_ff is not None:
-            g_ff = g_ff.contiguous().clone() if g_ff.is_contiguous() else g_ff.contiguous()
+            g_ff = g_ff.contiguous()
+        if g_ff0 is not None:
+            g_ff0 = g_ff0.contiguous()
+            if g_ff is None:
+                if g_ff0.shape[0] == ctx.saved.Bm:
+                    g_ff = g_ff0
+                else:
+                    g_ff = torch.zeros((ctx.saved.Bm,) + tuple(g_ff0.shape[1:]), device=g_ff0.device, dtype=g_ff0.dtype)
+                    g_ff[:g_ff0.shape[0]].copy_(g_ff0)
+            else:
+                ops.axpy(g_ff[:g_ff0.shape[0]], g_ff0, 1.0)
         if g_seg is not None:
             g_seg = g_seg.contiguous()
         grads = ctx.engine.backward(ctx.saved, g_seg if ctx.has[0] else None,
@@ -425,17 +445,17 @@ class WeatherNet(nn.Module):
         return self._engine
 
     def forward(self, left_img, return_supcon_feature=False):
-        ops.require_device(left_img, "left_img")
+        """left_img: [Bm,3,H,W] raw 0-255 image batch, or a list of batch parts (e.g. the two crops of the
+        ``supcon*`` criteria, equivalent to their torch.cat along dim 0 without the copy)."""
+        for t in (left_img if isinstance(left_img, (list, tuple)) else [left_img]):
+            ops.require_device(t, "left_img")
         params = [p for p in self.parameters()]
-        seg, before, ff = _SwiftNetFn.apply(self._get_engine(), left_img, self.training,
-                                            bool(return_supcon_feature), torch.is_grad_enabled(), *params)
-        # NHWC buffers exposed with the reference's logical NCHW shapes (channels_last strides, no copy)
+        seg, before, ff, ff0 = _SwiftNetFn.apply(self._get_engine(), left_img, self.training,
+                                                 bool(return_supcon_feature), torch.is_grad_enabled(), *params)
+        # NHWC buffers exposed with the reference's logical NCHW shapes (channels_last strides, no copy);
+        # fine_feat0 is the first half of fine_feat (weathernet.py:78-82) and shares its memory
         fine_feat = ff.permute(0, 3, 1, 2)
-        if return_supcon_feature:
-            bsz = fine_feat.shape[0] // 2
-            fine_feat0 = torch.split(fine_feat, [bsz, bsz], dim=0)[0]
-        else:
-            fine_feat0 = fine_feat
+        fine_feat0 = ff0.permute(0, 3, 1, 2)
         if self.segmentation is None:
             return None, None, fine_feat, fine_feat0
         pred_segmap_beforeup = before[..., :self.num_classes].permute(0, 3, 1, 2)

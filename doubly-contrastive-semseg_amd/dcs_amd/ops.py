@@ -196,7 +196,7 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate):
     M = N * g.DH * g.DW
     if R == 3 and S == 3 and stride == 1 and pad == 1 and W % 32 == 0:
         tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
-        ns = max(1, min(-(-1024 // tiles), M // 32))
+        ns = max(1, min(-(-1024 // tiles), M // 32))      # 1024 blocks = 2 full rounds of 2 blocks per CU
     else:
         bt = 128 if (Cout > 64 and Cin > 64) else 64
         tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
@@ -234,7 +234,7 @@ def stem_wgrad(p, dy, dwp, accumulate):
     N, H, W, _ = p.shape
     g = geom_stem(N, H, W)
     M = N * g.DH * g.DW
-    ns = _nsplit(7, M)
+    ns = max(1, min(512, M // 64)) if g.DW % 32 == 0 else _nsplit(7, M)   # seven-row stem kernel: one block per split
     slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(p), _p(dy), _p(slab), C.byref(g), 64, 0, ns, _stream())
     _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, _stream())
@@ -336,14 +336,24 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
 # pyramid / pooling / resize
 # --------------------------------------------------------------------------- #
 def normalize_pyramid(img, mean3, std3):
-    if not img.is_cuda or img.dtype != _F32:
-        raise RuntimeError("normalize_pyramid needs an fp32 device tensor")
-    img = img.contiguous()
-    N, Cc, H, W = img.shape
-    assert Cc == 3
-    mk = lambda h, w: torch.empty((N, h, w, 4), device=img.device, dtype=_F32)
+    """img: NCHW fp32 device tensor, or a list of such tensors (batch parts, e.g. the two crops): the parts are
+    normalised straight into one NHWC4 batch, so the caller needs no torch.cat copy."""
+    parts = list(img) if isinstance(img, (list, tuple)) else [img]
+    for t in parts:
+        if not t.is_cuda or t.dtype != _F32:
+            raise RuntimeError("normalize_pyramid needs fp32 device tensors (no CPU fallback)")
+    parts = [t.contiguous() for t in parts]
+    N = sum(t.shape[0] for t in parts)
+    _, Cc, H, W = parts[0].shape
+    assert Cc == 3 and all(t.shape[1:] == parts[0].shape[1:] for t in parts)
+    mk = lambda h, w: torch.empty((N, h, w, 4), device=parts[0].device, dtype=_F32)
     p0, p1, p2 = mk(H, W), mk(H // 2, W // 2), mk(H // 4, W // 4)
-    _call("dcs_normalize_pyramid", _p(img), _p(p0), _p(p1), _p(p2), N, H, W, _p(mean3), _p(std3), _stream())
+    b = 0
+    for t in parts:
+        n = t.shape[0]
+        _call("dcs_normalize_pyramid", _p(t), _p(p0[b:b + n]), _p(p1[b:b + n]), _p(p2[b:b + n]), n, H, W, _p(mean3),
+              _p(std3), _stream())
+        b += n
     return p0, p1, p2
 
 

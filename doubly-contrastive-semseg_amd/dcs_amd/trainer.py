@@ -88,17 +88,23 @@ class TrainStep:
     def step(self, sample, do_optimizer_step=True) -> Dict[str, torch.Tensor]:
         o = self.opts
         crit = o.criterion
-        if "supcon" in crit:                                       # trainer.py:66-72
+        dev = self.device
+        dt = getattr(o, "dtype", torch.float32)
+        if "supcon" in crit:                                       # trainer.py:66-72: cat of the two crops ...
             sample0, sample1 = sample
             sample = dict(sample0)
-            sample["left"] = torch.cat([sample0["left"], sample1["left"]], dim=0)
+            # ... expressed as a list of batch parts: the model normalises both crops into one batch directly
+            left = [sample0["left"].to(dev, dtype=dt), sample1["left"].to(dev, dtype=dt)]
+        else:
+            left = sample["left"].to(dev, dtype=dt)
         self.num_iter += 1
-        dev = self.device
-        left = sample["left"].to(dev, dtype=getattr(o, "dtype", torch.float32))
         labels = sample["label"].to(dev, dtype=torch.long)
         gt_weather = sample["weather"].to(dev) if "weather" in sample else None
         supcon_flag = "supcon" in crit
         left_seg, left_seg_beforeup, fine_feat, fine_feat0 = self.model(left, return_supcon_feature=supcon_flag)
+        if "pixelcontrast" in crit:
+            # start the sampler's counting kernel + D2H copy now so the host wait overlaps the other losses
+            self.pixelcontrast_criterion.prefetch(fine_feat0, labels, left_seg_beforeup)
         zero = torch.zeros(1, device=dev)
         out = dict(supcon=zero, simclr=zero, pixel=zero, seg=zero, ce=zero)
         if o.dataset == "acdc" and gt_weather is not None:        # trainer.py:109-114 (logged only)

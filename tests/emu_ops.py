@@ -181,6 +181,8 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
 
 
 def normalize_pyramid(img, mean3, std3):
+    if isinstance(img, (list, tuple)):
+        img = torch.cat(list(img), dim=0)
     x0 = (img - mean3.view(1, 3, 1, 1)) / std3.view(1, 3, 1, 1)
     outs = [x0] + [F.interpolate(x0, scale_factor=1 / 2 ** l, mode="bicubic", align_corners=None) for l in (1, 2)]
     return tuple(F.pad(_nhwc(o), (0, 1)).contiguous() for o in outs)

@@ -107,7 +107,7 @@ def test_conv_seg_head_19_classes_bias_and_padded_stride(ops):
     close(gx, E.conv_dgrad(dy, E.pack_dgrad_weight(w), (10, 12), 1, 0), what="dgrad cs20")
 
 
-@pytest.mark.parametrize("N,H,W", [(2, 32, 48), (1, 37, 29), (1, 8, 6)])
+@pytest.mark.parametrize("N,H,W", [(2, 32, 48), (1, 37, 29), (1, 8, 6), (2, 24, 64), (1, 10, 128), (3, 7, 192)])
 def test_stem_conv_and_wgrad(ops, N, H, W):
     p = torch.zeros(N, H, W, 4)
     p[..., :3] = rnd(N, H, W, 3, seed=9)
