@@ -283,15 +283,27 @@ class _PixelContrastFn(torch.autograd.Function):
 
 
 def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):
+    """See _plan_anchor_requests.  torch.randperm on CPU is thread-count independent in its RESULT but, with
+    several intra-op threads, takes 30-150 ms per call for 32K < n < 100K (measured, torch 2.10) instead of
+    0.3 ms; the plan therefore runs with one intra-op thread."""
+    nt = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        return _plan_anchor_requests(counts, num_classes, max_samples, max_views)
+    finally:
+        torch.set_num_threads(nt)
+
+
+def _plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):
     """Host half of utils/loss.py:264-337 given per-(image, class, hard|easy) pixel counts
     (int tensor [B, C, 2], index 0 = hard, 1 = easy).  Consumes the default CPU generator exactly
     like the reference (randperm(num_hard) then randperm(num_easy) per kept class).
 
     Returns None if no class qualifies, else (n_view, T, req [T*n_view, 3], cls [T], img [T]) with
     req rows (image, key = 2*class + is_easy, rank) in (t, view) order."""
-    B = counts.shape[0]
-    tot = counts.sum(-1)
-    classes = [[c for c in range(num_classes) if int(tot[ii, c]) > max_views] for ii in range(B)]
+    cl = counts.tolist()                                  # plain Python ints: no per-element tensor indexing
+    B = len(cl)
+    classes = [[c for c in range(num_classes) if cl[ii][c][0] + cl[ii][c][1] > max_views] for ii in range(B)]
     total_classes = sum(len(c) for c in classes)
     if total_classes == 0:
         return None
@@ -299,9 +311,10 @@ def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=102
     req: List[List[int]] = []
     cls: List[int] = []
     img: List[int] = []
+    randperm = torch.randperm
     for ii in range(B):
         for c in classes[ii]:
-            num_hard, num_easy = int(counts[ii, c, 0]), int(counts[ii, c, 1])
+            num_hard, num_easy = cl[ii][c]
             if num_hard >= n_view / 2 and num_easy >= n_view / 2:
                 num_hard_keep = n_view // 2
                 num_easy_keep = n_view - num_hard_keep
@@ -314,12 +327,14 @@ def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=102
             else:
                 print("this shoud be never touched! {} {} {}".format(num_hard, num_easy, n_view))
                 raise Exception
-            perm = torch.randperm(num_hard)
-            for r in perm[:num_hard_keep].tolist():
-                req.append([ii, 2 * c, r])
-            perm = torch.randperm(num_easy)
-            for r in perm[:num_easy_keep].tolist():
-                req.append([ii, 2 * c + 1, r])
+            perm = randperm(num_hard)                      # consumed even when nothing is kept, like the reference
+            if num_hard_keep > 0:
+                for r in perm[:num_hard_keep].tolist():
+                    req.append([ii, 2 * c, r])
+            perm = randperm(num_easy)
+            if num_easy_keep > 0:
+                for r in perm[:num_easy_keep].tolist():
+                    req.append([ii, 2 * c + 1, r])
             cls.append(c)
             img.append(ii)
     return n_view, total_classes, req, cls, img
