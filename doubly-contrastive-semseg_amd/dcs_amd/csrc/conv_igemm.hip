@@ -14,14 +14,13 @@
 // Global loads of chunk i+1 are issued before the 64 MFMAs of chunk i and written to the other
 // LDS buffer afterwards: one barrier per chunk.
 #include "dcs_common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
 constexpr int BM = 128;
-constexpr int BK = 32;
-constexpr int LDK = 36;   // LDS row stride in floats: 144 B = 9 x 16 B, odd in 16-B slots
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -40,8 +39,8 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BN, bool STEM>
-__global__ __launch_bounds__(256, 2)
+template <int BN, bool STEM, int BKT>
+__global__ __launch_bounds__(256, BKT == 16 ? 3 : 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                         const float* __restrict__ bias, float* __restrict__ dst,
                         const DcsConvGeom g, const int accumulate, const int ntiles) {
@@ -49,10 +48,16 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
-  constexpr int BROWS = BN / 32;
+  constexpr int LDKT = BKT + 4;          // LDS row stride: (BKT+4)*4 B is an odd number of 16-B slots (9 or 5)
+  constexpr int C4 = BKT / 4;            // float4 per staged row
+  constexpr int RPP = 256 / C4;          // rows staged per slot
+  constexpr int NA = BM / RPP;           // A slots per thread
+  constexpr int BROWS = BN / RPP;        // B slots per thread
+  constexpr int NG = BKT / 8;            // MFMA k8 groups per chunk
+  static_assert(BROWS >= 1 && (NG == 4 || NG == 2), "unsupported tile");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDK];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDK];
+  __shared__ __attribute__((aligned(16))) float As[2][BM * LDKT];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDKT];
   __shared__ long long rowoff[BM];
   __shared__ int s_oy[DCS_MAX_TAPS], s_ox[DCS_MAX_TAPS], s_wo[DCS_MAX_TAPS], s_to[DCS_MAX_TAPS];
 
@@ -60,7 +65,7 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   const int lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
-  const int lrow = tid >> 3, lcol4 = tid & 7;
+  const int lrow = tid / C4, lcol4 = tid % C4;
 
   const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = bid % ntiles, mtile = bid / ntiles;
@@ -92,10 +97,10 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     s_to[tid] = (g.offy[tid] * g.SW + g.offx[tid]) * g.src_cstride;
   }
 
-  int r_base[4], r_y[4], r_x[4];     // element offset of the row's (tap 0,0) source pixel; invalid rows: r_y = -2^20
+  int r_base[NA], r_y[NA], r_x[NA];  // element offset of the row's (tap 0,0) source pixel; invalid rows: r_y = -2^20
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned m = m0 + lrow + 32 * i;
+  for (int i = 0; i < NA; ++i) {
+    const unsigned m = m0 + lrow + RPP * i;
     const bool ok = m < M;
     const unsigned mm = ok ? m : m0;
     const int n = (int)(mm / TYX);
@@ -108,16 +113,16 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   int b_base[BROWS];                 // element offset of the weight row, or -1 beyond Cout
 #pragma unroll
   for (int i = 0; i < BROWS; ++i) {
-    const int co = co0 + lrow + 32 * i;
+    const int co = co0 + lrow + RPP * i;
     b_base[i] = co < g.Cout ? co * g.wstride : -1;
   }
   __syncthreads();
 
-  const int kch = STEM ? 1 : (g.K + BK - 1) / BK;
+  const int kch = STEM ? 1 : (g.K + BKT - 1) / BKT;
   const int nch = g.ntaps * kch;
 
-  // Register staging slots: 0..3 = the four A rows of this thread, 4.. = its B rows.
-  constexpr int NSLOT = 4 + BROWS;
+  // Register staging slots: 0..NA-1 = the A rows of this thread, NA.. = its B rows.
+  constexpr int NSLOT = NA + BROWS;
   float4 rs[NSLOT];
 
   // chunk -> (tap, channel offset); per-chunk scalars are refreshed once per chunk by set_chunk()
@@ -125,13 +130,13 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   bool c_kvalid = true;
   auto set_chunk = [&](int ch) {
     const int t = ch / kch;
-    const int c0 = (ch - t * kch) * BK;
+    const int c0 = (ch - t * kch) * BKT;
     c_oy = s_oy[t]; c_ox = s_ox[t]; c_wo = s_wo[t]; c_to = s_to[t];
     c_kc = c0 + lcol4 * 4;
     c_kvalid = STEM ? true : c_kc < g.K;
   };
   auto load_slot = [&](int sl) {
-    if (sl < 4) {
+    if (sl < NA) {
       const int i = sl;
       if (!STEM) {
         const bool ok = c_kvalid && (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH && (unsigned)(r_x[i] + c_ox) < (unsigned)g.SW;
@@ -142,13 +147,13 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
         rs[sl] = bld4(rsA, ok ? (unsigned)(r_base[i] + c_to + lcol4 * 4) * 4u : OOB);
       }
     } else {
-      const int i = sl - 4;
+      const int i = sl - NA;
       rs[sl] = bld4(rsB, (c_kvalid && b_base[i] >= 0) ? (unsigned)(b_base[i] + c_wo + c_kc) * 4u : OOB);
     }
   };
   auto store_slot = [&](int sl, int buf) {
-    if (sl < 4) *reinterpret_cast<float4*>(&As[buf][(lrow + 32 * sl) * LDK + lcol4 * 4]) = rs[sl];
-    else        *reinterpret_cast<float4*>(&Bs[buf][(lrow + 32 * (sl - 4)) * LDK + lcol4 * 4]) = rs[sl];
+    if (sl < NA) *reinterpret_cast<float4*>(&As[buf][(lrow + RPP * sl) * LDKT + lcol4 * 4]) = rs[sl];
+    else         *reinterpret_cast<float4*>(&Bs[buf][(lrow + RPP * (sl - NA)) * LDKT + lcol4 * 4]) = rs[sl];
   };
 
   f32x16 acc[TM][TN];
@@ -179,12 +184,12 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   auto frag_load = [&](int set, const float* Ab, const float* Bb, int kk) {
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      const float4 v = ld4(Ab + a * 32 * LDK + kk);
+      const float4 v = ld4(Ab + a * 32 * LDKT + kk);
       av[set][a][0] = v.x; av[set][a][1] = v.y; av[set][a][2] = v.z; av[set][a][3] = v.w;
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      const float4 v = ld4(Bb + b * 32 * LDK + kk);
+      const float4 v = ld4(Bb + b * 32 * LDKT + kk);
       bv[set][b][0] = v.x; bv[set][b][1] = v.y; bv[set][b][2] = v.z; bv[set][b][3] = v.w;
     }
   };
@@ -199,13 +204,13 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
 
   for (int ch = 0; ch < nch; ++ch) {
     const int buf = ch & 1;
-    const float* Ab = &As[buf][(wm * TM * 32 + l31) * LDK + 4 * h];
-    const float* Bb = &Bs[buf][(wn * TN * 32 + l31) * LDK + 4 * h];
+    const float* Ab = &As[buf][(wm * TM * 32 + l31) * LDKT + 4 * h];
+    const float* Bb = &Bs[buf][(wn * TN * 32 + l31) * LDKT + 4 * h];
     frag_load(0, Ab, Bb, 0);
     frag_load(1, Ab, Bb, 8);
     mfma_range(0, 0, G);
     set_chunk(ch + 2 < nch ? ch + 2 : nch - 1);
-    frag_load(0, Ab, Bb, 16);
+    if (NG == 4) frag_load(0, Ab, Bb, 16);
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
       store_slot(sl, buf ^ 1);
@@ -213,9 +218,11 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
       mfma_range(1, sl * G / NSLOT, (sl + 1) * G / NSLOT);
       __builtin_amdgcn_sched_barrier(0);
     }
-    frag_load(1, Ab, Bb, 24);
-    mfma_range(0, 0, G);
-    mfma_range(1, 0, G);
+    if (NG == 4) {
+      frag_load(1, Ab, Bb, 24);
+      mfma_range(0, 0, G);
+      mfma_range(1, 0, G);
+    }
     __syncthreads();
   }
 
@@ -788,6 +795,11 @@ int check_geom(const DcsConvGeom* g) {
 
 }  // namespace
 
+// K-chunk policy: 64-wide output tiles (64-channel layers, 1x1 skip convs) run the 16-channel chunk variant
+// (32.5 KB LDS -> 4 blocks per CU; measured +4 % on 3x3 64->64 and +27 % on the bandwidth-bound 1x1 64->128);
+// 128-wide tiles measure the same either way and keep 32-channel chunks.  DCS_CONV_BK16 forces 16 everywhere.
+static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
+
 extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
                                const DcsConvGeom* geom, int accumulate, void* stream) {
   int rc = check_geom(geom);
@@ -805,10 +817,13 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
 #define LAUNCH_GATHER(B)                                                                                              \
   do {                                                                                                                \
     if (geom->stem)                                                                                                   \
-      hipLaunchKernelGGL((conv_gather_kernel<B, true>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, \
-                         *geom, accumulate, ntiles);                                                                  \
+      hipLaunchKernelGGL((conv_gather_kernel<B, true, 32>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias,  \
+                         dst, *geom, accumulate, ntiles);                                                             \
+    else if (B == 64 || (B == 128 && g_bk16))                                                                         \
+      hipLaunchKernelGGL((conv_gather_kernel<(B >= 64 ? B : 64), false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, \
+                         src, wgt, bias, dst, *geom, accumulate, ntiles);                                             \
     else                                                                                                              \
-      hipLaunchKernelGGL((conv_gather_kernel<B, false>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias,     \
+      hipLaunchKernelGGL((conv_gather_kernel<B, false, 32>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, \
                          dst, *geom, accumulate, ntiles);                                                             \
   } while (0)
   if (bn == 128)

@@ -80,11 +80,22 @@ class DataParallelStep:
         ts.ce_criterion.dist_reduce = red
         self.params: List[torch.nn.Parameter] = [p for p in ts.model.parameters()]
         # identical initial parameters / buffers on every rank
-        for t in list(ts.model.parameters()) + list(ts.model.buffers()) + list(ts.supcon_criterion.parameters()):
-            dist.broadcast(t.data, src=0, group=group)
+        flat = getattr(ts, "flat", None)
+        tensors = ([g["flat_p"] for g in flat.groups] if flat is not None else [p.data for p in ts.model.parameters()])
+        tensors += [b for b in ts.model.buffers()] + [p.data for p in ts.supcon_criterion.parameters()]
+        for t in tensors:
+            dist.broadcast(t, src=0, group=group)
         self._flat = None
 
     def _allreduce_grads(self):
+        flat = getattr(self.ts, "flat", None)
+        if flat is not None and all(flat.aliased([p for p in g["params"]]) for g in flat.groups
+                                    if any(p.grad is not None for p in g["params"])):
+            # gradients already live in the flat per-group buffers: all-reduce them in place, no copy
+            for g in flat.groups:
+                if any(p.grad is not None for p in g["params"]):
+                    dist.all_reduce(g["flat_g"], op=dist.ReduceOp.SUM, group=self.group)
+            return
         ps = [p for p in self.params if p.grad is not None]
         n = sum(p.numel() for p in ps)
         if self._flat is None or self._flat.numel() != n:

@@ -130,6 +130,36 @@ class ResNetPyramid(nn.Module):
 
 
 # --------------------------------------------------------------------------- #
+class FlatBuffers:
+    """Parameters of each optimizer group re-homed as views of ONE flat fp32 buffer (element order = each
+    parameter's own storage order, i.e. KRSC for conv weights), with a same-shaped flat gradient buffer.
+    The backward pass writes gradients straight into the gradient views; Adam is then one kernel launch per
+    group and the data-parallel all-reduce runs on the flat gradient buffer without a copy."""
+
+    def __init__(self, groups: List[List[nn.Parameter]]):
+        self.groups = []
+        self.grad_view: Dict[nn.Parameter, torch.Tensor] = {}
+        for ps in groups:
+            ps = list(ps)
+            if not ps:
+                continue
+            n = sum(p.numel() for p in ps)
+            flat_p = torch.empty(n, device=ps[0].device, dtype=ps[0].dtype)
+            flat_g = torch.zeros(n, device=ps[0].device, dtype=ps[0].dtype)
+            off = 0
+            for p in ps:
+                v = torch.as_strided(flat_p, p.size(), p.stride(), off)
+                v.copy_(p.data)
+                p.data = v
+                self.grad_view[p] = torch.as_strided(flat_g, p.size(), p.stride(), off)
+                off += p.numel()
+            self.groups.append(dict(params=ps, flat_p=flat_p, flat_g=flat_g))
+
+    def aliased(self, ps) -> bool:
+        return all(p.grad is not None and p in self.grad_view and p.grad.data_ptr() == self.grad_view[p].data_ptr()
+                   for p in ps)
+
+
 class _Saved:
     __slots__ = ("tape", "shapes", "training", "B", "Bm")
 
@@ -140,6 +170,11 @@ class SwiftNetEngine:
     def __init__(self, fe: ResNetPyramid, seg: Optional[_BNReluConv], num_classes: int):
         self.fe, self.seg, self.num_classes = fe, seg, num_classes
         self._mean = self._std = None
+        self.flat: Optional[FlatBuffers] = None
+
+    def _galloc(self, p):
+        v = self.flat.grad_view.get(p) if self.flat is not None else None
+        return v if v is not None else torch.empty_like(p)
 
     # ---- helpers ---------------------------------------------------------
     def _bn(self, x, m: nn.BatchNorm2d, training, rows=None):
@@ -249,7 +284,7 @@ class SwiftNetEngine:
             w = conv.weight
             acc = w in grads
             if not acc:
-                grads[w] = torch.empty_like(w)
+                grads[w] = self._galloc(w)
             ops.conv_wgrad(x, dy, grads[w], stride, pad, acc)
 
         def wp(conv):
@@ -261,8 +296,8 @@ class SwiftNetEngine:
         def bn_bwd(m: nn.BatchNorm2d, g, y, bn, **kw):
             acc = m.weight in grads
             if not acc:
-                grads[m.weight] = torch.empty_like(m.weight)
-                grads[m.bias] = torch.empty_like(m.bias)
+                grads[m.weight] = self._galloc(m.weight)
+                grads[m.bias] = self._galloc(m.bias)
             return ops.bn_bwd(g, y, bn, m.weight, dgamma=grads[m.weight], dbeta=grads[m.bias], acc_param=acc,
                               training=training, **kw)
 
@@ -287,7 +322,8 @@ class SwiftNetEngine:
                 seg = self.seg
                 wgrad(seg.conv, zh, gb, 1, 0)
                 bsum = ops.colsum(gb.reshape(-1, LOGIT_CS))
-                grads[seg.conv.bias] = bsum[0, 0, :self.num_classes].clone()
+                grads[seg.conv.bias] = self._galloc(seg.conv.bias)
+                grads[seg.conv.bias].copy_(bsum[0, 0, :self.num_classes])
                 wpad = torch.zeros((NUM_FEATURES, 1, 1, LOGIT_CS), device=gb.device, dtype=gb.dtype)
                 wpad[..., :self.num_classes] = wp(seg.conv)
                 g_zh = ops.conv_dgrad(gb, wpad, (h, w), 1, 0)
@@ -362,7 +398,8 @@ class SwiftNetEngine:
             else:  # pragma: no cover
                 raise RuntimeError(kind)
         if dwst is not None:
-            grads[self.fe.conv1.weight] = ops.unpack_stem_weight(dwst, self.fe.conv1.weight)
+            grads[self.fe.conv1.weight] = ops.unpack_stem_weight(dwst, self.fe.conv1.weight,
+                                                                 out=self._galloc(self.fe.conv1.weight))
         self._flush_nbt()
         return grads
 
@@ -407,7 +444,20 @@ class _SwiftNetFn(torch.autograd.Function):
         grads = ctx.engine.backward(ctx.saved, g_seg if ctx.has[0] else None,
                                     g_before if (ctx.has[1] and g_before is not None) else None, g_ff)
         ctx.saved = None
-        return (None, None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
+        flat = ctx.engine.flat
+        res = []
+        for p in ctx.params:
+            gp = grads.get(p)
+            if gp is not None and flat is not None and flat.grad_view.get(p) is gp:
+                # gradient already sits in the flat buffer: publish it as .grad without autograd's copy
+                if p.grad is None:
+                    p.grad = gp
+                elif p.grad.data_ptr() != gp.data_ptr():
+                    p.grad.add_(gp)
+                res.append(None)
+            else:
+                res.append(gp)
+        return (None, None, None, None, None) + tuple(res)
 
 
 class WeatherNet(nn.Module):
@@ -466,6 +516,14 @@ class WeatherNet(nn.Module):
 
     def fine_tune_params(self):
         return self.feature_extractor.fine_tune_params()
+
+    def flatten_parameters(self):
+        """Optional (call after ``.to(device)``): re-home the parameters of the two ADAM groups
+        (utils/init_trainer.py:169-177) and of the segmentation head in flat buffers, see FlatBuffers."""
+        rest = [p for p in (self.segmentation.parameters() if self.segmentation is not None else [])]
+        flat = FlatBuffers([list(self.random_init_params()), list(self.fine_tune_params()), rest])
+        self._get_engine().flat = flat
+        return flat
 
 
 class WeatherClassifier(nn.Module):

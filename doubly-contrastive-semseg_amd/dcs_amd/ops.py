@@ -213,8 +213,8 @@ def pack_stem_weight(w):
     return o
 
 
-def unpack_stem_weight(wp, like):
-    o = torch.empty_like(like)           # preserves channels_last
+def unpack_stem_weight(wp, like, out=None):
+    o = out if out is not None else torch.empty_like(like)           # preserves channels_last
     _call("dcs_pack_stem_weight", _p(wp), _p(krsc(o)), wp.shape[0], 1, _stream())
     return o
 

@@ -37,13 +37,32 @@ def make_opts(**kw):
 class DcsAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (L2 weight decay folded into the gradient) on the fused HIP kernel."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, flat=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat = flat                      # model.FlatBuffers or None
+        self._flat_state = {}
+
+    def _flat_group(self, group):
+        if self.flat is None:
+            return None
+        for fg in self.flat.groups:
+            if len(fg["params"]) == len(group["params"]) and all(a is b for a, b in zip(fg["params"], group["params"])):
+                return fg
+        return None
 
     @torch.no_grad()
     def step(self, closure=None):
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             b1, b2 = group["betas"]
+            fg = self._flat_group(group)
+            if fg is not None and self.flat.aliased(group["params"]):
+                # every gradient of the group lives in the flat buffer: ONE fused launch for the whole group
+                st = self._flat_state.setdefault(gi, dict(step=0, m=torch.zeros_like(fg["flat_p"]),
+                                                           v=torch.zeros_like(fg["flat_p"])))
+                st["step"] += 1
+                ops.adam_step(fg["flat_p"], fg["flat_g"], st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"],
+                              float(group["weight_decay"]), st["step"])
+                continue
             for p in group["params"]:
                 if p.grad is None:
                     continue
@@ -78,10 +97,11 @@ class TrainStep:
         self.pixelcontrast_criterion = PixelContrastLoss(device=self.device)
         self.ce_criterion = SemsegCrossEntropy(num_classes=opts.num_classes, ignore_id=255)
         fine_tune_factor = 4                                       # utils/init_trainer.py:169-177
+        self.flat = self.model.flatten_parameters() if getattr(opts, "flat_params", True) else None
         self.optimizer = DcsAdam([
             {"params": list(self.model.random_init_params()), "lr": opts.lr, "weight_decay": opts.weight_decay},
             {"params": list(self.model.fine_tune_params()), "lr": opts.lr / fine_tune_factor,
-             "weight_decay": opts.weight_decay / fine_tune_factor}], betas=(0.9, 0.99))
+             "weight_decay": opts.weight_decay / fine_tune_factor}], betas=(0.9, 0.99), flat=self.flat)
         self.num_iter = 0
         self.model.train()
 

@@ -71,8 +71,8 @@ def pack_stem_weight(w):
     return F.pad(w.permute(0, 2, 3, 1), (0, 1, 0, 1)).contiguous()   # [64,7,8,4]
 
 
-def unpack_stem_weight(wp, like):
-    o = torch.empty_like(like)
+def unpack_stem_weight(wp, like, out=None):
+    o = out if out is not None else torch.empty_like(like)
     o.copy_(wp[:, :, :7, :3].permute(0, 3, 1, 2))
     return o
 

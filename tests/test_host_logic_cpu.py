@@ -105,7 +105,8 @@ def test_engine_matches_oracle_fp64_odd_size(emu, criterion, two):
     img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=31, two_crops=two, cell=16)
     state = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in O.make_state(seed=1).items()}
     proj = [p.to(dt) for p in O.make_proj(seed=2)]
-    ts = TrainStep(make_opts(criterion=criterion, batch_size=b, dtype=dt), class_weight=cw.to(dt), device="cpu")
+    ts = TrainStep(make_opts(criterion=criterion, batch_size=b, dtype=dt, flat_params=False), class_weight=cw.to(dt),
+                   device="cpu")          # flat buffers are fp32 views; this test casts the modules to float64
     ts.model.double(); ts.supcon_criterion.double(); ts.weather_clf.double()
     ts.model.load_state_dict(state, strict=True)
     with torch.no_grad():
