@@ -35,8 +35,8 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16, help="labelled images per GPU (each contributes two crops)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
@@ -71,19 +71,21 @@ class ConvProfiler:
                 g = args[4]._obj if name == "dcs_conv_gather" else args[3]._obj
                 M = g.N * g.TY * g.TX
                 flops = 2.0 * M * (147 if g.stem else g.ntaps * g.K) * g.Cout
+                # algorithmic bytes: gathered tensor once + produced tensor once + weights once
+                abytes = 4.0 * (g.N * g.SH * g.SW * (3 if g.stem else g.K) + M * g.Cout + g.Cout * g.wstride)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self._orig(name, *args)
                 e1.record()
                 key = (name, g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy, g.stem)
-                self.records.append((name, flops, e0, e1, key))
+                self.records.append((name, flops, e0, e1, key, abytes))
             else:
                 self._orig(name, *args)
         ops._call = wrapped
 
     def per_shape(self):
         agg = {}
-        for name, flops, e0, e1, key in self.records:
+        for name, flops, e0, e1, key, _ in self.records:
             a = agg.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
         rows = []
@@ -103,7 +105,8 @@ class ConvProfiler:
             ms = sum(r[2].elapsed_time(r[3]) for r in rs)
             fl = sum(r[1] for r in rs)
             out[name] = dict(launches=len(rs), ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
-                             avg_us=ms * 1e3 / len(rs))
+                             avg_us=ms * 1e3 / len(rs), alg_bytes_per_launch=sum(r[5] for r in rs) / len(rs),
+                             alg_flops_per_launch=fl / len(rs))
         return out
 
 
@@ -129,6 +132,17 @@ def cpu_baseline(O, args):
     return {"value": b / sec, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{args.cpu_steps} timed steps (1 warm-up) of B={b} labelled image ({2 if two else 1} crops) at "
                       f"{args.width}x{args.height}, {args.criterion}, oracle/swiftnet_oracle.py on torch CPU"}
+
+
+def pmc_traffic(args, world):
+    """HBM bytes per conv_gather launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+    separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
+    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_c3.json")
+    default = (args.batch, args.height, args.width, args.criterion) == (16, 1024, 2048, "supcon_pixelcontrast_focal")
+    if not (default and os.path.exists(path)):
+        return None
+    with open(path) as f:
+        return json.load(f)["conv_gather"]["hbm_bytes_per_launch"]
 
 
 def main():
@@ -173,8 +187,11 @@ def main():
     torch.cuda.synchronize()
     prof.enabled = True
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks[0].record()
+    for i in range(args.steps):
         out = one_step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -187,6 +204,8 @@ def main():
         dt = float(t)
     loss = float(out["total"])
     if rank == 0:
+        print("[bench] per-step GPU ms: " + " ".join(f"{marks[i].elapsed_time(marks[i + 1]):.1f}" for i in range(args.steps)),
+              file=sys.stderr, flush=True)
         ms = dt / args.steps * 1e3
         value = b * world * args.steps / dt
         ps = prof.summary()
@@ -205,7 +224,10 @@ def main():
                        "conv_tflops_per_gpu_whole_step": value * crops * 769.2e9 * (args.height * args.width / (1024 * 2048)) / 1e12 / world,
                        "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": g["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": g["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": g["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(args, world),
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c_pmc_traffic_c3.json)",
+                         "algorithmic_bytes_per_launch": g.get("alg_bytes_per_launch"),
+                         "algorithmic_flops_per_launch": g.get("alg_flops_per_launch"),
                          "kernel": "conv_gather_kernel (conv forward + data gradient, fp32 MFMA 32x32x2)",
                          "launches_per_step": g["launches"] // max(args.steps, 1), "avg_launch_us": g["avg_us"],
                          "ms_per_step": g["ms"] / max(args.steps, 1),
