@@ -43,7 +43,7 @@ template <int BN, bool STEM, int BKT>
 __global__ __launch_bounds__(256, BKT == 16 ? 3 : 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                         const float* __restrict__ bias, float* __restrict__ dst,
-                        const DcsConvGeom g, const int accumulate, const int ntiles) {
+                        const DcsConvGeom g, const int accumulate, const int ntiles, float* __restrict__ stats) {
   constexpr int WN = BN >= 64 ? 2 : 1;
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (WM * 32);
@@ -226,25 +226,49 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // With `stats`, the per-channel sum and sum of squares of this block's outputs (the BatchNorm batch statistics
+  // of the layer that follows) are reduced here in fixed order and written to stats[mtile][2][Cout], so the
+  // activation is not read again by a separate reduction pass.
+  float* st = &As[0][0];                 // [WM][BN][2] scratch, free after the final barrier of the main loop
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = co0 + wn * TN * 32 + b * 32 + l31;
-      if (col >= g.Cout) continue;
+  for (int b = 0; b < TN; ++b) {
+    const int cl = wn * TN * 32 + b * 32 + l31;
+    const int col = co0 + cl;
+    float ssum = 0.f, ssq = 0.f;
+    if (col < g.Cout) {
       const float bv = bias ? bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const long long ro = rowoff[row];
-        if (ro < 0) continue;
-        float* p = dst + ro + col;
-        float v = acc[a][b][r] + bv;
-        if (accumulate) v += *p;
-        *p = v;
-      }
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const long long ro = rowoff[row];
+          if (ro < 0) continue;
+          float* p = dst + ro + col;
+          float v = acc[a][b][r] + bv;
+          if (accumulate) v += *p;
+          *p = v;
+          ssum += v;
+          ssq = fmaf(v, v, ssq);
+        }
     }
+    if (stats) {
+      ssum += __shfl_xor(ssum, 32, 64);
+      ssq += __shfl_xor(ssq, 32, 64);
+      if (h == 0) { st[(wm * BN + cl) * 2] = ssum; st[(wm * BN + cl) * 2 + 1] = ssq; }
+    }
+  }
+  if (stats) {
+    __syncthreads();
+    if (tid < BN && co0 + tid < g.Cout) {
+      float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) { s0 += st[(w * BN + tid) * 2]; s1 += st[(w * BN + tid) * 2 + 1]; }
+      stats[((long long)mtile * 2) * g.Cout + co0 + tid] = s0;
+      stats[((long long)mtile * 2 + 1) * g.Cout + co0 + tid] = s1;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -801,7 +825,7 @@ int check_geom(const DcsConvGeom* g) {
 static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
 
 extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
-                               const DcsConvGeom* geom, int accumulate, void* stream) {
+                               const DcsConvGeom* geom, int accumulate, float* stats, void* stream) {
   int rc = check_geom(geom);
   if (rc != DCS_OK) return rc;
   DCS_CHECK_ARG(src && wgt && dst && dcs_aligned16(src) && dcs_aligned16(wgt));
@@ -818,13 +842,13 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   do {                                                                                                                \
     if (geom->stem)                                                                                                   \
       hipLaunchKernelGGL((conv_gather_kernel<B, true, 32>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias,  \
-                         dst, *geom, accumulate, ntiles);                                                             \
+                         dst, *geom, accumulate, ntiles, stats);                                                      \
     else if (B == 64 || (B == 128 && g_bk16))                                                                         \
       hipLaunchKernelGGL((conv_gather_kernel<(B >= 64 ? B : 64), false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, \
-                         src, wgt, bias, dst, *geom, accumulate, ntiles);                                             \
+                         src, wgt, bias, dst, *geom, accumulate, ntiles, stats);                                      \
     else                                                                                                              \
       hipLaunchKernelGGL((conv_gather_kernel<B, false, 32>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, \
-                         dst, *geom, accumulate, ntiles);                                                             \
+                         dst, *geom, accumulate, ntiles, stats);                                                      \
   } while (0)
   if (bn == 128)
     LAUNCH_GATHER(128);

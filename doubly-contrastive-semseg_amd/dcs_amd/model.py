@@ -177,11 +177,14 @@ class SwiftNetEngine:
         return v if v is not None else torch.empty_like(p)
 
     # ---- helpers ---------------------------------------------------------
-    def _bn(self, x, m: nn.BatchNorm2d, training, rows=None):
+    def _bn(self, x, m: nn.BatchNorm2d, training, rows=None, sums=None):
+        """BatchNorm record [scale, shift, mean, invstd] of x; ``sums`` = statistics already reduced by the
+        producing convolution's epilogue (otherwise a reduction pass over x)."""
         Cc = x.shape[-1]
         rows = rows if rows is not None else x.numel() // Cc
         if training:
-            sums = ops.colsum(x.reshape(-1, Cc)[:rows])
+            if sums is None:
+                sums = ops.colsum(x.reshape(-1, Cc)[:rows])
             bn = ops.bn_finalize(sums, m.weight, m.bias, m.running_mean, m.running_var, rows, True,
                                  momentum=m.momentum)
             self._nbt.append(m)
@@ -208,9 +211,9 @@ class SwiftNetEngine:
         wst = ops.pack_stem_weight(fe.conv1.weight)
         skips: List[List[torch.Tensor]] = [[] for _ in range(6)]
         for idx, p in enumerate(pyr):
-            y = ops.stem_conv(p, wst)
             bnm = getattr(fe, f"bn1_{idx}")
-            bn = self._bn(y, bnm, training)
+            y, st = ops.stem_conv(p, wst, want_stats=True) if training else (ops.stem_conv(p, wst), None)
+            bn = self._bn(y, bnm, training, sums=st)
             x, pidx = ops.bn_relu_maxpool(y, bn)
             if need_grad:
                 tape.append(("stem", idx, p, y, bn, pidx, bnm))
@@ -256,15 +259,19 @@ class SwiftNetEngine:
 
     def _block_fwd(self, x, blk: BasicBlock, training, tape):
         s = blk.stride
-        y1 = ops.conv_fwd(x, blk.conv1.weight, s, 1)
-        bn1 = self._bn(y1, blk.bn1, training)
+
+        def conv(inp, w, stride, pad):        # conv + (in training) the BN batch statistics from its epilogue
+            return ops.conv_fwd(inp, w, stride, pad, want_stats=True) if training else (ops.conv_fwd(inp, w, stride, pad), None)
+
+        y1, st1 = conv(x, blk.conv1.weight, s, 1)
+        bn1 = self._bn(y1, blk.bn1, training, sums=st1)
         z1 = ops.bn_act(y1, bn1, relu=True)
-        y2 = ops.conv_fwd(z1, blk.conv2.weight, 1, 1)
-        bn2 = self._bn(y2, blk.bn2, training)
+        y2, st2 = conv(z1, blk.conv2.weight, 1, 1)
+        bn2 = self._bn(y2, blk.bn2, training, sums=st2)
         yd = bnd = None
         if blk.downsample is not None:
-            yd = ops.conv_fwd(x, blk.downsample[0].weight, s, 0)
-            bnd = self._bn(yd, blk.downsample[1], training)
+            yd, std_ = conv(x, blk.downsample[0].weight, s, 0)
+            bnd = self._bn(yd, blk.downsample[1], training, sums=std_)
             out = ops.bn_act(y2, bn2, r=yd, bn2=bnd, relu=True)
         else:
             out = ops.bn_act(y2, bn2, r=x, relu=True)

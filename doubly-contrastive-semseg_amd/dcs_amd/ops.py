@@ -128,8 +128,33 @@ def geom_stem(N, H, W):
 # --------------------------------------------------------------------------- #
 # convolution
 # --------------------------------------------------------------------------- #
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None):
-    """nn.Conv2d forward.  x [N,H,W,Cin]; w OIHW channels_last; -> [N,OH,OW,dst_cs or Cout]."""
+CONV_BM = 128
+
+
+def _stats_buffer(M, Cout, dev):
+    """Per-row-tile partial sums written by the conv epilogue, padded so they reduce in <= 2 fixed-order levels."""
+    G = -(-M // CONV_BM)
+    if G <= 2048:
+        return torch.empty((G, 2, Cout), device=dev, dtype=_F32), G, 0
+    G1 = -(-G // 128)
+    return torch.zeros((G1 * 128, 2, Cout), device=dev, dtype=_F32), G, G1
+
+
+def _stats_reduce(part, G, G1, Cout):
+    """-> sums [1, 2, Cout] (sum, sum of squares) over all rows, deterministic."""
+    out = torch.empty((1, 2, Cout), device=part.device, dtype=_F32)
+    if G1 == 0:
+        _call("dcs_colsum_final", _p(part), _p(out), 1, G, Cout, 1.0, _stream())
+    else:
+        mid = torch.empty((G1, 2, Cout), device=part.device, dtype=_F32)
+        _call("dcs_colsum_final", _p(part), _p(mid), G1, 128, Cout, 1.0, _stream())
+        _call("dcs_colsum_final", _p(mid), _p(out), 1, G1, Cout, 1.0, _stream())
+    return out
+
+
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False):
+    """nn.Conv2d forward.  x [N,H,W,Cin]; w OIHW channels_last; -> [N,OH,OW,dst_cs or Cout].
+    want_stats: also return sums [1,2,Cout] (per-channel sum / sum of squares of the output) from the fused epilogue."""
     _req(x)
     N, H, W, Cin = x.shape
     Cout, _, R, S = w.shape
@@ -137,8 +162,12 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None):
     cs = dst_cs or Cout
     alloc = torch.zeros if cs != Cout else torch.empty
     y = alloc((N, g.DH, g.DW, cs), device=x.device, dtype=_F32)
-    _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, _stream())
-    return y
+    if not want_stats:
+        _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, None, _stream())
+        return y
+    part, G, G1 = _stats_buffer(N * g.DH * g.DW, Cout, x.device)
+    _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, _p(part), _stream())
+    return y, _stats_reduce(part, G, G1, Cout)
 
 
 def pack_dgrad_weight(w):
@@ -167,7 +196,7 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
             continue
         if cs != g.src_cstride:
             g = _with_src_cs(g, cs)
-        _call("dcs_conv_gather", _p(dy), _p(wp), None, _p(out), C.byref(g), 1 if accumulate else 0, _stream())
+        _call("dcs_conv_gather", _p(dy), _p(wp), None, _p(out), C.byref(g), 1 if accumulate else 0, None, _stream())
     return out
 
 
@@ -219,14 +248,18 @@ def unpack_stem_weight(wp, like, out=None):
     return o
 
 
-def stem_conv(p, wp):
+def stem_conv(p, wp, want_stats=False):
     """7x7/2 pad 3 conv on the NHWC4 normalised image; wp = pack_stem_weight(conv1.weight)."""
     _req(p)
     N, H, W, _ = p.shape
     g = geom_stem(N, H, W)
     y = torch.empty((N, g.DH, g.DW, 64), device=p.device, dtype=_F32)
-    _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, _stream())
-    return y
+    if not want_stats:
+        _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, None, _stream())
+        return y
+    part, G, G1 = _stats_buffer(N * g.DH * g.DW, 64, p.device)
+    _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, _p(part), _stream())
+    return y, _stats_reduce(part, G, G1, 64)
 
 
 def stem_wgrad(p, dy, dwp, accumulate):
@@ -246,7 +279,7 @@ def linear(x, w, bias=None):
     Cout = w.shape[0]
     g = geom_fwd(rows, 1, 1, K, Cout, 1, 1, 1, 0)
     y = torch.empty((rows, Cout), device=x.device, dtype=_F32)
-    _call("dcs_conv_gather", _p(_req(x)), _p(_req(w)), _p(bias), _p(y), C.byref(g), 0, _stream())
+    _call("dcs_conv_gather", _p(_req(x)), _p(_req(w)), _p(bias), _p(y), C.byref(g), 0, None, _stream())
     return y
 
 
@@ -480,7 +513,7 @@ def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     # S = X X^T on the MFMA GEMM (1x1 conv with the anchors as weights)
     g = geom_fwd(A, 1, 1, Cc, A, 1, 1, 1, 0, None, ld)
     S = torch.empty((A, ld), device=X.device, dtype=_F32)
-    _call("dcs_conv_gather", _p(X), _p(X), None, _p(S), C.byref(g), 0, _stream())
+    _call("dcs_conv_gather", _p(X), _p(X), None, _p(S), C.byref(g), 0, None, _stream())
     loss_row = torch.empty((A,), device=X.device, dtype=_F32)
     G = torch.empty((A, ld), device=X.device, dtype=_F32)
     _call("dcs_contrast_rows", _p(S), _p(labels), _p(loss_row), _p(G), A, ld, mode, 1.0 / temperature, _stream())
@@ -496,7 +529,7 @@ def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     Xt = transpose(Xp)                                   # [C, ld]
     g2 = geom_fwd(A, 1, 1, ld, Cc, 1, 1, 1, 0)
     dX = torch.empty((A, Cc), device=X.device, dtype=_F32)
-    _call("dcs_conv_gather", _p(Gs), _p(Xt), None, _p(dX), C.byref(g2), 0, _stream())
+    _call("dcs_conv_gather", _p(Gs), _p(Xt), None, _p(dX), C.byref(g2), 0, None, _stream())
     return loss, dX
 
 

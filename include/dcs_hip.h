@@ -59,9 +59,12 @@ typedef struct DcsConvGeom {
 /* ---- convolution as implicit GEMM on v_mfma_f32_32x32x2_f32 --------------------------------
  * replaces nn.Conv2d forward (network/backbone/resnet_pyramid.py:23-25,:139,:110-112;
  * network/utils.py:46-47) and the data half of aten::convolution_backward.
- * dst[m, co] (+)= bias[co] + sum_t sum_k src[gather(m,t), k] * wgt[co, wofs[t]+k]              */
+ * dst[m, co] (+)= bias[co] + sum_t sum_k src[gather(m,t), k] * wgt[co, wofs[t]+k]
+ * stats (nullable): [ceil(M/DCS_CONV_BM)][2][Cout] per-row-tile sums / sums of squares of the values written
+ * (the batch statistics of the BatchNorm that follows); reduce them with dcs_colsum_final.             */
+#define DCS_CONV_BM 128
 int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
-                    const DcsConvGeom* geom, int accumulate, void* stream);
+                    const DcsConvGeom* geom, int accumulate, float* stats, void* stream);
 
 /* Weight gradient, split over pixel ranges.  slab[split][co][wstride] receives partial sums for
  * split = split0 .. split0+nsplit-1 (every element of those slab slices is written).

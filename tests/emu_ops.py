@@ -31,11 +31,12 @@ def krsc(w):
     return w.permute(0, 2, 3, 1)
 
 
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None):
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False):
     y = _nhwc(F.conv2d(_nchw(x), w, bias, stride, pad))
+    sums = colsum(y.reshape(-1, y.shape[-1])) if want_stats else None
     if dst_cs and dst_cs != y.shape[-1]:
         y = F.pad(y, (0, dst_cs - y.shape[-1]))
-    return y.contiguous()
+    return (y.contiguous(), sums) if want_stats else y.contiguous()
 
 
 def pack_dgrad_weight(w):
@@ -81,8 +82,9 @@ def _stem_w(wp):
     return wp[:, :, :7, :3].permute(0, 3, 1, 2).contiguous()
 
 
-def stem_conv(p, wp):
-    return _nhwc(F.conv2d(_nchw(p[..., :3]), _stem_w(wp), None, 2, 3))
+def stem_conv(p, wp, want_stats=False):
+    y = _nhwc(F.conv2d(_nchw(p[..., :3]), _stem_w(wp), None, 2, 3))
+    return (y, colsum(y.reshape(-1, 64))) if want_stats else y
 
 
 def stem_wgrad(p, dy, dwp, accumulate):

@@ -55,6 +55,7 @@ CONV_CASES = [
     (1, 5, 32, 128, 64, 3, 1),
     (3, 3, 96, 64, 128, 3, 1),
     (1, 2, 32, 256, 256, 3, 1),
+    (3, 300, 320, 64, 64, 1, 1),     # 2250 row tiles: two-level reduction of the fused BN statistics
 ]
 
 
@@ -66,6 +67,9 @@ def test_conv_fwd_dgrad_wgrad(ops, N, H, W, Cin, Cout, k, s):
     y_ref = E.conv_fwd(x, w, s, pad)
     y = ops.conv_fwd(x.to(DEV), cl(w.to(DEV)), s, pad)
     close(y, y_ref, what="fwd")
+    y2, sums = ops.conv_fwd(x.to(DEV), cl(w.to(DEV)), s, pad, want_stats=True)
+    close(y2, y_ref, what="fwd with stats epilogue")
+    close(sums, E.colsum(y_ref.reshape(-1, Cout)), 1e-5, "fused BN statistics")
     dy = rnd(*y_ref.shape, seed=3)
     wp_ref = E.pack_dgrad_weight(w)
     wp = ops.pack_dgrad_weight(cl(w.to(DEV)))
@@ -114,9 +118,10 @@ def test_stem_conv_and_wgrad(ops, N, H, W):
     w = cl(rnd(64, 3, 7, 7, seed=10, scale=0.1))
     wp = ops.pack_stem_weight(cl(w.to(DEV)))
     close(wp, E.pack_stem_weight(w), 0.0, "pack stem")
-    y = ops.stem_conv(p.to(DEV), wp)
+    y, sums = ops.stem_conv(p.to(DEV), wp, want_stats=True)
     yref = E.stem_conv(p, E.pack_stem_weight(w))
     close(y, yref, what="stem fwd")
+    close(sums, E.colsum(yref.reshape(-1, 64)), 1e-5, "stem fused BN statistics")
     dy = rnd(*yref.shape, seed=11)
     dwp = torch.empty(64, 7, 8, 4, device=DEV)
     ops.stem_wgrad(p.to(DEV), dy.to(DEV), dwp, False)
