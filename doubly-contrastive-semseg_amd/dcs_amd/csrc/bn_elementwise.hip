@@ -10,13 +10,16 @@ namespace {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
-// partial[b][g][2][C]
+// partial[b][g][2][C].  Channels are processed in blocks of <= 512 (blockIdx.z) so that any C % 4 == 0 works
+// (ResNet-101 has 2048-channel BatchNorms).
 template <int MODE>
 __global__ __launch_bounds__(256)
 void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                            const float* __restrict__ masksrc, const float* __restrict__ bn,
-                           float* __restrict__ partial, long long rows, int C, int cstride, int groups, int relu) {
+                           float* __restrict__ partial, long long rows, int Ctot, int cstride, int groups, int relu) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][RL][C]
+  const int cbase = blockIdx.z * 512;
+  const int C = Ctot - cbase < 512 ? Ctot - cbase : 512;
   const int C4 = C >> 2;
   const int RL = 256 / C4;
   const int tid = threadIdx.x;
@@ -25,13 +28,14 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
   const long long rpg = (rows + groups - 1) / groups;
   const long long rbeg = (long long)gi * rpg;
   const long long rend = rbeg + rpg < rows ? rbeg + rpg : rows;
-  const float* xb = x + (long long)b * rows * cstride;
+  const float* xb = x + (long long)b * rows * cstride + cbase;
   float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
   if (rl < RL) {
     float4 sc, sh, mu, is;
     if (MODE == 1) {
-      sc = ld4(bn + col4 * 4); sh = ld4(bn + C + col4 * 4);
-      mu = ld4(bn + 2 * C + col4 * 4); is = ld4(bn + 3 * C + col4 * 4);
+      const int cc = cbase + col4 * 4;
+      sc = ld4(bn + cc); sh = ld4(bn + Ctot + cc);
+      mu = ld4(bn + 2 * Ctot + cc); is = ld4(bn + 3 * Ctot + cc);
     }
     for (long long r = rbeg + rl; r < rend; r += RL) {
       const long long off = r * cstride + col4 * 4;
@@ -41,9 +45,9 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
         s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y);
         s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
       } else {
-        const float4 yy = ld4(y + off);
+        const float4 yy = ld4(y + cbase + off);
         if (masksrc) {
-          const float4 ms = ld4(masksrc + off);
+          const float4 ms = ld4(masksrc + cbase + off);
           v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f;
           v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
         } else if (relu) {
@@ -63,7 +67,7 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
     const int which = t / C, c = t - which * C;
     float s = 0.f;
     for (int k = 0; k < RL; ++k) s += sm[(which * RL + k) * C + c];
-    partial[(((long long)b * groups + gi) * 2 + which) * C + c] = s;
+    partial[(((long long)b * groups + gi) * 2 + which) * Ctot + cbase + c] = s;
   }
 }
 
@@ -242,6 +246,31 @@ __global__ void relu_bwd_kernel(const float* __restrict__ g, const float* __rest
     out[i] = z[i] > 0.f ? g[i] : 0.f;
 }
 
+// nn.Dropout: out = x * noise * scale, noise in {0,1}.  noise == null: the keep mask is generated on the fly from a
+// counter-based hash of (seed, element index) and written to mask_out (uint8) for the backward pass.
+__device__ __forceinline__ unsigned pcg_hash(unsigned v) {
+  unsigned s = v * 747796405u + 2891336453u;
+  unsigned w = ((s >> ((s >> 28u) + 4u)) ^ s) * 277803737u;
+  return (w >> 22u) ^ w;
+}
+__global__ void dropout_kernel(const float* __restrict__ x, const float* __restrict__ noise,
+                               unsigned char* __restrict__ mask_out, float* __restrict__ out, long long n, float p,
+                               float scale, unsigned seed) {
+  const unsigned thr = (unsigned)((double)p * 4294967296.0);
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float keep;
+    if (noise) keep = noise[i];
+    else keep = pcg_hash(seed ^ pcg_hash((unsigned)i) ^ (unsigned)(i >> 32)) >= thr ? 1.f : 0.f;
+    if (mask_out) mask_out[i] = keep != 0.f;
+    out[i] = x[i] * keep * scale;
+  }
+}
+__global__ void dropout_bwd_kernel(const float* __restrict__ g, const unsigned char* __restrict__ mask,
+                                   float* __restrict__ out, long long n, float scale) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+    out[i] = mask[i] ? g[i] * scale : 0.f;
+}
+
 __global__ void sum_scalar_kernel(const float* __restrict__ x, float* __restrict__ out, int n, float scale) {
   __shared__ double sm[256];
   double s = 0.0;
@@ -280,12 +309,13 @@ inline unsigned grid_for(long long n, int per = 256, unsigned cap = 8192) {
 extern "C" int dcs_colsum_partial(const float* x, const float* y, const float* masksrc, const float* bn,
                                   float* partial, int B, int64_t rows, int C, int cstride, int groups, int mode,
                                   int relu, void* stream) {
-  DCS_CHECK_ARG(x && partial && B > 0 && rows > 0 && groups > 0 && C > 0 && (C & 3) == 0 && C <= 512);
+  DCS_CHECK_ARG(x && partial && B > 0 && rows > 0 && groups > 0 && C > 0 && (C & 3) == 0 && C <= 8192);
   DCS_CHECK_ARG((cstride & 3) == 0 && cstride >= C && dcs_aligned16(x));
   DCS_CHECK_ARG(mode == 0 || (mode == 1 && y && bn && cstride == C));
-  const int C4 = C / 4, RL = 256 / C4;
-  const size_t sh = (size_t)2 * RL * C * sizeof(float);
-  dim3 grid((unsigned)groups, (unsigned)B);
+  const int Cb = C < 512 ? C : 512;
+  const int C4 = Cb / 4, RL = 256 / C4;
+  const size_t sh = (size_t)2 * RL * Cb * sizeof(float);
+  dim3 grid((unsigned)groups, (unsigned)B, (unsigned)((C + 511) / 512));
   if (mode == 0)
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), sh, dcs_stream(stream), x, y, masksrc, bn, partial,
                        (long long)rows, C, cstride, groups, relu);
@@ -363,6 +393,21 @@ extern "C" int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW,
 extern "C" int dcs_relu_bwd_rows(const float* g, const float* z, float* out, int64_t n, void* stream) {
   DCS_CHECK_ARG(g && z && out && n > 0);
   hipLaunchKernelGGL(relu_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), g, z, out, (long long)n);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_dropout(const float* x, const float* noise, uint8_t* mask_out, float* out, int64_t n, float p,
+                           uint32_t seed, void* stream) {
+  DCS_CHECK_ARG(x && out && n > 0 && p >= 0.f && p < 1.f && (noise || mask_out));
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), x, noise, mask_out, out,
+                     (long long)n, p, 1.f / (1.f - p), seed);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_dropout_bwd(const float* g, const uint8_t* mask, float* out, int64_t n, float p, void* stream) {
+  DCS_CHECK_ARG(g && mask && out && n > 0 && p >= 0.f && p < 1.f);
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), g, mask, out, (long long)n,
+                     1.f / (1.f - p));
   DCS_LAUNCH_RET();
 }
 

@@ -726,7 +726,7 @@ void stem_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
 // sl, sl+4, ... with independent loads in flight, then the 4 partial sums are added in fixed order (deterministic).
 __global__ __launch_bounds__(256)
 void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nsplit,
-                        int accumulate) {
+                        int accumulate, int row_len, int dst_stride) {
   __shared__ float sm[4][64];
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const long long i = (long long)blockIdx.x * 64 + c;
@@ -747,13 +747,16 @@ void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, 
   __syncthreads();
   if (sl == 0 && i < n) {
     const float t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
-    dw[i] = (accumulate ? dw[i] : 0.f) + t;
+    // row_len > 0: the slab holds compact rows of row_len floats that land at stride dst_stride in dw
+    // (a channel slice of a wider weight tensor, used for "virtual concat" convolutions)
+    const long long o = row_len > 0 ? (i / row_len) * dst_stride + (i % row_len) : i;
+    dw[o] = (accumulate ? dw[o] : 0.f) + t;
   }
 }
 
 __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int Cout, int RS,
-                                         int Cin) {
-  // o[ci][rs][co] = w[co][rs][ci]; thread per output element, co fastest
+                                         int Cin, int cin_total, int cin_off) {
+  // o[ci][rs][co] = w[co][rs][cin_off + ci] (w rows have cin_total channels); thread per output element, co fastest
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long n = (long long)Cout * RS * Cin;
   if (i >= n) return;
@@ -761,7 +764,7 @@ __global__ void pack_dgrad_weight_kernel(const float* __restrict__ w, float* __r
   const long long q = i / Cout;
   const int rs = (int)(q % RS);
   const int ci = (int)(q / RS);
-  o[i] = w[((long long)co * RS + rs) * Cin + ci];
+  o[i] = w[((long long)co * RS + rs) * cin_total + cin_off + ci];
 }
 
 __global__ void pack_stem_weight_kernel(const float* __restrict__ in, float* __restrict__ out, int Cout, int dir) {
@@ -908,19 +911,20 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
   DCS_LAUNCH_RET();
 }
 
-extern "C" int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, void* stream) {
-  DCS_CHECK_ARG(slab && dw && n > 0 && nsplit > 0);
+extern "C" int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, int row_len,
+                               int dst_stride, void* stream) {
+  DCS_CHECK_ARG(slab && dw && n > 0 && nsplit > 0 && row_len >= 0 && (row_len == 0 || (dst_stride >= row_len && n % row_len == 0)));
   hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, dcs_stream(stream), slab, dw,
-                     (long long)n, nsplit, accumulate);
+                     (long long)n, nsplit, accumulate, row_len, dst_stride);
   DCS_LAUNCH_RET();
 }
 
 extern "C" int dcs_pack_dgrad_weight(const float* w_krsc, float* w_crsk, int Cout, int R, int S, int Cin,
-                                     void* stream) {
-  DCS_CHECK_ARG(w_krsc && w_crsk && Cout > 0 && R > 0 && S > 0 && Cin > 0);
+                                     int cin_total, int cin_off, void* stream) {
+  DCS_CHECK_ARG(w_krsc && w_crsk && Cout > 0 && R > 0 && S > 0 && Cin > 0 && cin_off >= 0 && cin_off + Cin <= cin_total);
   const long long n = (long long)Cout * R * S * Cin;
   hipLaunchKernelGGL(pack_dgrad_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, dcs_stream(stream),
-                     w_krsc, w_crsk, Cout, R * S, Cin);
+                     w_krsc, w_crsk, Cout, R * S, Cin, cin_total, cin_off);
   DCS_LAUNCH_RET();
 }
 

@@ -32,8 +32,8 @@ _G = C.POINTER(DcsConvGeom)
 SIGNATURES = {
     "dcs_conv_gather": [_P, _P, _P, _P, _G, _I, _P, _P],
     "dcs_conv_wgrad": [_P, _P, _P, _G, _I, _I, _I, _P],
-    "dcs_reduce_slab": [_P, _P, _L, _I, _I, _P],
-    "dcs_pack_dgrad_weight": [_P, _P, _I, _I, _I, _I, _P],
+    "dcs_reduce_slab": [_P, _P, _L, _I, _I, _I, _I, _P],
+    "dcs_pack_dgrad_weight": [_P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dcs_pack_stem_weight": [_P, _P, _I, _I, _P],
     "dcs_transpose": [_P, _P, _I, _I, _P],
     "dcs_colsum_partial": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P],
@@ -59,6 +59,8 @@ SIGNATURES = {
     "dcs_contrast_rows": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "dcs_symmetrize": [_P, _P, _I, _I, _P],
     "dcs_sum_scalar": [_P, _P, _I, _F, _P],
+    "dcs_dropout": [_P, _P, _P, _P, _L, _F, C.c_uint32, _P],
+    "dcs_dropout_bwd": [_P, _P, _P, _L, _F, _P],
     "dcs_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "dcs_axpy": [_P, _P, _L, _F, _P],
     "dcs_add_rowvec_bcast": [_P, _P, _I, _L, _I, _F, _P],

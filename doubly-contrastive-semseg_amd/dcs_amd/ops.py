@@ -78,33 +78,40 @@ def out_size(n, k, stride, pad):
     return (n + 2 * pad - k) // stride + 1
 
 
-def geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, src_cs=None, dst_cs=None):
-    key = ("f", N, H, W, Cin, Cout, R, S, stride, pad, src_cs, dst_cs)
+def out_size_d(n, k, stride, pad, dil):
+    return (n + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+def geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, src_cs=None, dst_cs=None, dil=1, koff=0, ktot=None):
+    """Forward gather geometry.  dil: dilation.  (koff, ktot): the Cin source channels multiply the weight channel
+    slice [koff, koff+Cin) of rows that hold ktot channels per tap ("virtual concat" along the input channels)."""
+    ktot = ktot or Cin
+    key = ("f", N, H, W, Cin, Cout, R, S, stride, pad, src_cs, dst_cs, dil, koff, ktot)
     g = _geom_cache.get(key)
     if g is None:
-        OH, OW = out_size(H, R, stride, pad), out_size(W, S, stride, pad)
-        taps = [(r - pad, s - pad, (r * S + s) * Cin) for r in range(R) for s in range(S)]
-        g = _mk_geom(N, H, W, OH, OW, OH, OW, stride, 1, 0, 0, Cin, Cout, taps, R * S * Cin,
+        OH, OW = out_size_d(H, R, stride, pad, dil), out_size_d(W, S, stride, pad, dil)
+        taps = [(r * dil - pad, s * dil - pad, (r * S + s) * ktot + koff) for r in range(R) for s in range(S)]
+        g = _mk_geom(N, H, W, OH, OW, OH, OW, stride, 1, 0, 0, Cin, Cout, taps, R * S * ktot,
                      src_cs or Cin, dst_cs or Cout)
         _geom_cache[key] = g
     return g
 
 
-def geoms_dgrad(N, IH, IW, Cin, Cout, R, S, stride, pad):
+def geoms_dgrad(N, IH, IW, Cin, Cout, R, S, stride, pad, dil=1):
     """One geometry per input parity class (no wasted taps for stride 2)."""
-    key = ("d", N, IH, IW, Cin, Cout, R, S, stride, pad)
+    key = ("d", N, IH, IW, Cin, Cout, R, S, stride, pad, dil)
     gs = _geom_cache.get(key)
     if gs is None:
-        OH, OW = out_size(IH, R, stride, pad), out_size(IW, S, stride, pad)
+        OH, OW = out_size_d(IH, R, stride, pad, dil), out_size_d(IW, S, stride, pad, dil)
         gs = []
         for py in range(stride):
             for px in range(stride):
                 TY, TX = -(-(IH - py) // stride), -(-(IW - px) // stride)
                 if TY <= 0 or TX <= 0:
                     continue
-                taps = [((py + pad - r) // stride, (px + pad - s) // stride, (r * S + s) * Cout)
+                taps = [((py + pad - r * dil) // stride, (px + pad - s * dil) // stride, (r * S + s) * Cout)
                         for r in range(R) for s in range(S)
-                        if (py + pad - r) % stride == 0 and (px + pad - s) % stride == 0]
+                        if (py + pad - r * dil) % stride == 0 and (px + pad - s * dil) % stride == 0]
                 if not taps:
                     gs.append(None)
                     continue
@@ -152,14 +159,20 @@ def _stats_reduce(part, G, G1, Cout):
     return out
 
 
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False):
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None):
     """nn.Conv2d forward.  x [N,H,W,Cin]; w OIHW channels_last; -> [N,OH,OW,dst_cs or Cout].
-    want_stats: also return sums [1,2,Cout] (per-channel sum / sum of squares of the output) from the fused epilogue."""
+    want_stats: also return sums [1,2,Cout] (per-channel sum / sum of squares of the output) from the fused epilogue.
+    koff: x holds the input-channel slice [koff, koff+Cin) of a wider weight (the other slices belong to other
+    tensors of a concatenation); out: accumulate into this tensor instead of allocating (sum over the slices)."""
     _req(x)
     N, H, W, Cin = x.shape
-    Cout, _, R, S = w.shape
-    g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, None, dst_cs)
+    Cout, Ktot, R, S = w.shape
+    g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, None, dst_cs, dil, koff or 0, Ktot)
     cs = dst_cs or Cout
+    if out is not None:
+        assert not want_stats
+        _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(out), C.byref(g), 1, None, _stream())
+        return out
     alloc = torch.zeros if cs != Cout else torch.empty
     y = alloc((N, g.DH, g.DW, cs), device=x.device, dtype=_F32)
     if not want_stats:
@@ -170,21 +183,22 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False):
     return y, _stats_reduce(part, G, G1, Cout)
 
 
-def pack_dgrad_weight(w):
-    """[Cout,R,S,Cin] -> [Cin,R,S,Cout] for the data-gradient GEMM."""
-    Cout, Cin, R, S = w.shape
-    o = torch.empty((Cin, R, S, Cout), device=w.device, dtype=_F32)
-    _call("dcs_pack_dgrad_weight", _p(krsc(w)), _p(o), Cout, R, S, Cin, _stream())
+def pack_dgrad_weight(w, koff=0, kw=None):
+    """[Cout,R,S,koff:koff+kw] -> [kw,R,S,Cout] for the data-gradient GEMM (whole weight by default)."""
+    Cout, Ktot, R, S = w.shape
+    kw = kw or Ktot
+    o = torch.empty((kw, R, S, Cout), device=w.device, dtype=_F32)
+    _call("dcs_pack_dgrad_weight", _p(krsc(w)), _p(o), Cout, R, S, kw, Ktot, koff, _stream())
     return o
 
 
-def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None):
+def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None, dil=1):
     """Data gradient.  dy [N,OH,OW,cs>=Cout]; wp = pack_dgrad_weight(w) [Cin,R,S,Cout]."""
     _req(dy)
     N = dy.shape[0]
     Cin, R, S, Cout = wp.shape
     IH, IW = in_hw
-    gs = geoms_dgrad(N, IH, IW, Cin, Cout, R, S, stride, pad)
+    gs = geoms_dgrad(N, IH, IW, Cin, Cout, R, S, stride, pad, dil)
     if out is None:
         accumulate = False
         out = (torch.zeros if any(g is None for g in gs) else torch.empty)((N, IH, IW, Cin), device=dy.device, dtype=_F32)
@@ -216,14 +230,15 @@ def _nsplit(tiles, M):
     return max(1, min(-(-1024 // tiles), -(-M // 256)))
 
 
-def conv_wgrad(x, dy, dw, stride, pad, accumulate):
-    """Weight gradient into dw (OIHW channels_last, same layout as the parameter)."""
+def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
+    """Weight gradient into dw (OIHW channels_last, same layout as the parameter).  koff: x is the input-channel
+    slice [koff, koff+Cin) of the convolution, only that slice of dw is written."""
     _req(x), _req(dy)
     N, H, W, Cin = x.shape
-    Cout, _, R, S = dw.shape
-    g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad)
+    Cout, Ktot, R, S = dw.shape
+    g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, None, None, dil)       # compact slab rows of R*S*Cin
     M = N * g.DH * g.DW
-    if R == 3 and S == 3 and stride == 1 and pad == 1 and W % 32 == 0:
+    if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 32 == 0:
         tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
         ns = max(1, min(-(-1024 // tiles), M // 32))      # 1024 blocks = 2 full rounds of 2 blocks per CU
     else:
@@ -233,7 +248,11 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate):
     n = Cout * R * S * Cin
     slab = torch.empty((ns, n), device=x.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())
-    _call("dcs_reduce_slab", _p(slab), _p(krsc(dw)), n, ns, 1 if accumulate else 0, _stream())
+    if koff is None and Ktot == Cin:
+        _call("dcs_reduce_slab", _p(slab), _p(krsc(dw)), n, ns, 1 if accumulate else 0, 0, 0, _stream())
+    else:
+        dst = C.c_void_p(krsc(dw).data_ptr() + 4 * (koff or 0))
+        _call("dcs_reduce_slab", _p(slab), dst, n, ns, 1 if accumulate else 0, Cin, Ktot, _stream())
 
 
 def pack_stem_weight(w):
@@ -270,7 +289,7 @@ def stem_wgrad(p, dy, dwp, accumulate):
     ns = max(1, min(512, M // 64)) if g.DW % 32 == 0 else _nsplit(7, M)   # seven-row stem kernel: one block per split
     slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(p), _p(dy), _p(slab), C.byref(g), 64, 0, ns, _stream())
-    _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, _stream())
+    _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, 0, 0, _stream())
 
 
 def linear(x, w, bias=None):
@@ -298,7 +317,7 @@ def linear_wgrad(x, dy, dw, accumulate=False):
     ns = 1
     slab = torch.empty((ns, Cout * K), device=x.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(_req(x)), _p(_req(dy)), _p(slab), C.byref(g), Cout, 0, ns, _stream())
-    _call("dcs_reduce_slab", _p(slab), _p(dw), Cout * K, ns, 1 if accumulate else 0, _stream())
+    _call("dcs_reduce_slab", _p(slab), _p(dw), Cout * K, ns, 1 if accumulate else 0, 0, 0, _stream())
 
 
 # --------------------------------------------------------------------------- #
@@ -368,8 +387,9 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
 # --------------------------------------------------------------------------- #
 # pyramid / pooling / resize
 # --------------------------------------------------------------------------- #
-def normalize_pyramid(img, mean3, std3):
-    """img: NCHW fp32 device tensor, or a list of such tensors (batch parts, e.g. the two crops): the parts are
+def normalize_pyramid(img, mean3, std3, levels=3):
+    """levels=1: only the full-resolution NHWC4 image (DeepLab: no pyramid; mean 0 / std 1 = plain repack).
+    img: NCHW fp32 device tensor, or a list of such tensors (batch parts, e.g. the two crops): the parts are
     normalised straight into one NHWC4 batch, so the caller needs no torch.cat copy."""
     parts = list(img) if isinstance(img, (list, tuple)) else [img]
     for t in parts:
@@ -380,12 +400,13 @@ def normalize_pyramid(img, mean3, std3):
     _, Cc, H, W = parts[0].shape
     assert Cc == 3 and all(t.shape[1:] == parts[0].shape[1:] for t in parts)
     mk = lambda h, w: torch.empty((N, h, w, 4), device=parts[0].device, dtype=_F32)
-    p0, p1, p2 = mk(H, W), mk(H // 2, W // 2), mk(H // 4, W // 4)
+    p0 = mk(H, W)
+    p1, p2 = (mk(H // 2, W // 2), mk(H // 4, W // 4)) if levels == 3 else (None, None)
     b = 0
     for t in parts:
         n = t.shape[0]
-        _call("dcs_normalize_pyramid", _p(t), _p(p0[b:b + n]), _p(p1[b:b + n]), _p(p2[b:b + n]), n, H, W, _p(mean3),
-              _p(std3), _stream())
+        _call("dcs_normalize_pyramid", _p(t), _p(p0[b:b + n]), _p(p1[b:b + n]) if p1 is not None else None,
+              _p(p2[b:b + n]) if p2 is not None else None, n, H, W, _p(mean3), _p(std3), _stream())
         b += n
     return p0, p1, p2
 
@@ -531,6 +552,22 @@ def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     dX = torch.empty((A, Cc), device=X.device, dtype=_F32)
     _call("dcs_conv_gather", _p(Gs), _p(Xt), None, _p(dX), C.byref(g2), 0, None, _stream())
     return loss, dX
+
+
+def dropout(x, p, noise=None, seed=0):
+    """nn.Dropout forward.  noise: optional float 0/1 keep tensor (same shape, e.g. drawn on the host from the CPU
+    generator like the reference); otherwise a device-side counter-based mask from ``seed``.  -> (out, mask uint8)."""
+    _req(x)
+    out = torch.empty_like(x)
+    mask = torch.empty(x.shape, device=x.device, dtype=torch.uint8)
+    _call("dcs_dropout", _p(x), _p(noise), _p(mask), _p(out), x.numel(), float(p), int(seed) & 0xFFFFFFFF, _stream())
+    return out, mask
+
+
+def dropout_bwd(g, mask, p):
+    out = torch.empty_like(g)
+    _call("dcs_dropout_bwd", _p(_req(g)), _p(mask), _p(out), g.numel(), float(p), _stream())
+    return out
 
 
 def sum_scalar(x, scale=1.0):

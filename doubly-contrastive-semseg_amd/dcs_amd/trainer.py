@@ -29,7 +29,7 @@ def make_opts(**kw):
     d = dict(model="resnet18", deeplab=False, criterion="supcon_pixelcontrast_focal", batch_size=8, lr=4e-4,
              weight_decay=1e-4, optimizer_policy="ADAM", dataset="acdc", weather_num=4, num_classes=19,
              train_semantic=True, with_depth_level_loss=False, no_class_weights=False, no_EDT=False,
-             epochs=400, last_lr=1e-6)
+             epochs=400, last_lr=1e-6, output_stride=16)
     d.update(kw)
     return types.SimpleNamespace(**d)
 
@@ -84,8 +84,13 @@ class TrainStep:
         self.opts = opts
         self.device = torch.device(device)
         opts.weight = class_weight
-        self.model = WeatherNet(opts, num_classes=opts.num_classes, device=self.device, backbone=opts.model,
-                                train_semantic=opts.train_semantic).to(self.device)
+        if getattr(opts, "deeplab", False):                          # utils/init_trainer.py:99-102
+            from . import deeplab
+            self.model = getattr(deeplab, opts.model)(opts, num_classes=opts.num_classes,
+                                                      output_stride=opts.output_stride).to(self.device)
+        else:
+            self.model = WeatherNet(opts, num_classes=opts.num_classes, device=self.device, backbone=opts.model,
+                                    train_semantic=opts.train_semantic).to(self.device)
         self.weather_clf = WeatherClassifier(opts, weather_class_num=opts.weather_num).to(self.device)
         w = class_weight
         self.criterion = BoundaryAwareFocalLoss(gamma=0.5, num_classes=opts.num_classes, ignore_id=255, weight=w,
@@ -98,10 +103,14 @@ class TrainStep:
         self.ce_criterion = SemsegCrossEntropy(num_classes=opts.num_classes, ignore_id=255)
         fine_tune_factor = 4                                       # utils/init_trainer.py:169-177
         self.flat = self.model.flatten_parameters() if getattr(opts, "flat_params", True) else None
-        self.optimizer = DcsAdam([
-            {"params": list(self.model.random_init_params()), "lr": opts.lr, "weight_decay": opts.weight_decay},
-            {"params": list(self.model.fine_tune_params()), "lr": opts.lr / fine_tune_factor,
-             "weight_decay": opts.weight_decay / fine_tune_factor}], betas=(0.9, 0.99), flat=self.flat)
+        if getattr(opts, "deeplab", False):                          # utils/init_trainer.py:163-168: one group
+            groups = [{"params": list(self.model.parameters()), "lr": opts.lr, "weight_decay": opts.weight_decay}]
+        else:
+            groups = [
+                {"params": list(self.model.random_init_params()), "lr": opts.lr, "weight_decay": opts.weight_decay},
+                {"params": list(self.model.fine_tune_params()), "lr": opts.lr / fine_tune_factor,
+                 "weight_decay": opts.weight_decay / fine_tune_factor}]
+        self.optimizer = DcsAdam(groups, betas=(0.9, 0.99), flat=self.flat)
         self.num_iter = 0
         self.model.train()
 

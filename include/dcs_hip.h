@@ -72,11 +72,16 @@ int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float
 int dcs_conv_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom,
                    int dy_cstride, int split0, int nsplit, void* stream);
 
-/* dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i], fixed order (deterministic). */
-int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, void* stream);
+/* dw[o(i)] = (accumulate ? dw[o(i)] : 0) + sum_s slab[s][i], fixed order (deterministic).
+ * row_len == 0: o(i) = i.  row_len > 0: the slab holds compact rows of row_len floats that land at stride
+ * dst_stride in dw (gradient of a channel slice of a wider weight, "virtual concat" convolutions). */
+int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, int row_len,
+                    int dst_stride, void* stream);
 
-/* [Cout][R][S][Cin] -> [Cin][R][S][Cout] (weights for the data-gradient GEMM). */
-int dcs_pack_dgrad_weight(const float* w_krsc, float* w_crsk, int Cout, int R, int S, int Cin, void* stream);
+/* [Cout][R][S][cin_off .. cin_off+Cin) of rows with cin_total channels -> [Cin][R][S][Cout]
+ * (weights for the data-gradient GEMM; cin_total = Cin, cin_off = 0 for a whole weight). */
+int dcs_pack_dgrad_weight(const float* w_krsc, float* w_crsk, int Cout, int R, int S, int Cin, int cin_total,
+                          int cin_off, void* stream);
 /* stem: [64][7][7][3] <-> [64][7][8][4] zero padded (dir 0: pack, 1: unpack). */
 int dcs_pack_stem_weight(const float* in, float* out, int Cout, int dir, void* stream);
 /* out[c][r] = in[r][c]  (in: [R][C]) */
@@ -179,6 +184,14 @@ int dcs_contrast_rows(const float* S, const float* labels, float* loss_row, floa
 int dcs_symmetrize(const float* G, float* Gs, int A, int ld, void* stream);
 /* out[0] = scale * sum x[0..n) in double (single block, deterministic). */
 int dcs_sum_scalar(const float* x, float* out, int n, float scale, void* stream);
+
+/* ---- dropout (nn.Dropout(0.1) of network/_deeplab.py:164) ------------------------------------------
+ * out = x * keep / (1-p).  noise != null: keep = noise[i] (0/1 floats supplied by the caller, e.g. drawn from the
+ * CPU generator like the reference); else keep is a counter-based hash of (seed, i).  mask_out (uint8, nullable
+ * when noise is given) receives keep for dcs_dropout_bwd: out = mask ? g / (1-p) : 0. */
+int dcs_dropout(const float* x, const float* noise, uint8_t* mask_out, float* out, int64_t n, float p,
+                uint32_t seed, void* stream);
+int dcs_dropout_bwd(const float* g, const uint8_t* mask, float* out, int64_t n, float p, void* stream);
 
 /* ---- optimizer (torch.optim.Adam semantics, utils/init_trainer.py:169-177) ------------------*/
 int dcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,

@@ -31,24 +31,29 @@ def krsc(w):
     return w.permute(0, 2, 3, 1)
 
 
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False):
-    y = _nhwc(F.conv2d(_nchw(x), w, bias, stride, pad))
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None):
+    wk = w if koff is None else w[:, koff:koff + x.shape[-1]]
+    y = _nhwc(F.conv2d(_nchw(x), wk, bias, stride, pad, dil))
+    if out is not None:
+        out[..., :y.shape[-1]].add_(y)
+        return out
     sums = colsum(y.reshape(-1, y.shape[-1])) if want_stats else None
     if dst_cs and dst_cs != y.shape[-1]:
         y = F.pad(y, (0, dst_cs - y.shape[-1]))
     return (y.contiguous(), sums) if want_stats else y.contiguous()
 
 
-def pack_dgrad_weight(w):
-    return w.permute(1, 2, 3, 0).contiguous()          # [Cin,R,S,Cout]
+def pack_dgrad_weight(w, koff=0, kw=None):
+    kw = kw or w.shape[1]
+    return w[:, koff:koff + kw].permute(1, 2, 3, 0).contiguous()          # [Cin,R,S,Cout]
 
 
-def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None):
+def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None, dil=1):
     Cin, R, S, Cout = wp.shape
     w = wp.permute(3, 0, 1, 2)[:, :, :, :]              # [Cout,Cin,R,S]
     N = dy.shape[0]
     g = torch.nn.grad.conv2d_input((N, Cin, in_hw[0], in_hw[1]), w.contiguous(), _nchw(dy[..., :Cout]).contiguous(),
-                                   stride, pad)
+                                   stride, pad, dil)
     g = _nhwc(g)
     if out is None:
         return g
@@ -59,13 +64,16 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
     return out
 
 
-def conv_wgrad(x, dy, dw, stride, pad, accumulate):
+def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
     Cout = dw.shape[0]
-    g = torch.nn.grad.conv2d_weight(_nchw(x).contiguous(), dw.shape, _nchw(dy[..., :Cout]).contiguous(), stride, pad)
+    Cin = x.shape[-1]
+    shape = (Cout, Cin) + tuple(dw.shape[2:])
+    g = torch.nn.grad.conv2d_weight(_nchw(x).contiguous(), shape, _nchw(dy[..., :Cout]).contiguous(), stride, pad, dil)
+    tgt = dw if (koff is None and dw.shape[1] == Cin) else dw[:, (koff or 0):(koff or 0) + Cin]
     if accumulate:
-        dw.add_(g)
+        tgt.add_(g)
     else:
-        dw.copy_(g)
+        tgt.copy_(g)
 
 
 def pack_stem_weight(w):
@@ -182,9 +190,12 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
     return dy, (gm.contiguous() if want_gm else None)
 
 
-def normalize_pyramid(img, mean3, std3):
+def normalize_pyramid(img, mean3, std3, levels=3):
     if isinstance(img, (list, tuple)):
         img = torch.cat(list(img), dim=0)
+    if levels == 1:
+        x0 = (img - mean3.view(1, 3, 1, 1)) / std3.view(1, 3, 1, 1)
+        return F.pad(_nhwc(x0), (0, 1)).contiguous(), None, None
     x0 = (img - mean3.view(1, 3, 1, 1)) / std3.view(1, 3, 1, 1)
     outs = [x0] + [F.interpolate(x0, scale_factor=1 / 2 ** l, mode="bicubic", align_corners=None) for l in (1, 2)]
     return tuple(F.pad(_nhwc(o), (0, 1)).contiguous() for o in outs)
@@ -327,6 +338,17 @@ def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     loss = (-(pos * lp).sum(1) / pos.sum(1)).mean()
     (dX,) = torch.autograd.grad(loss, x)
     return loss.detach().reshape(1), dX.contiguous()
+
+
+def dropout(x, p, noise=None, seed=0):
+    if noise is None:
+        g = torch.Generator().manual_seed(int(seed))
+        noise = torch.empty(x.shape, dtype=x.dtype).bernoulli_(1 - p, generator=g)
+    return x * noise / (1 - p), (noise != 0).to(torch.uint8)
+
+
+def dropout_bwd(g, mask, p):
+    return g * mask.to(g.dtype) / (1 - p)
 
 
 def sum_scalar(x, scale=1.0):

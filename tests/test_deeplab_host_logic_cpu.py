@@ -1,0 +1,84 @@
+"""CPU: host logic of the DeepLabV3+/ResNet-101 engine (dcs_amd/deeplab.py) with emulated kernels:
+  * fp32 against the golden vectors produced by the reference's own model (config 5),
+  * float64 against the oracle at a non-multiple-of-32 size (exactness of the hand-written backward,
+    dilated convolutions, virtual concatenations, dropout mask hand-off)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import emu_ops
+from oracle import deeplab_oracle as D
+from oracle import swiftnet_oracle as O
+from test_deeplab_oracle_golden import oracle_deeplab_step
+
+
+@pytest.fixture()
+def emu(monkeypatch):
+    emu_ops.install(monkeypatch)
+
+
+def build(dt=torch.float32, flat=True, b=2, cw=None):
+    from dcs_amd.trainer import TrainStep, make_opts
+    opts = make_opts(criterion="supcon_pixelcontrast_focal", batch_size=b, deeplab=True, model="deeplabv3plus_resnet101",
+                     dtype=dt, flat_params=flat)
+    ts = TrainStep(opts, class_weight=cw, device="cpu")
+    if dt == torch.float64:
+        ts.model.double(); ts.supcon_criterion.double(); ts.weather_clf.double()
+    state = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in D.make_state(seed=7).items()}
+    ts.model.load_state_dict(state, strict=True)
+    proj = [p.to(dt) for p in O.make_proj(seed=9, dim_in=2048)]
+    with torch.no_grad():
+        p = ts.supcon_criterion.projection
+        for dst, src in zip((p[0].weight, p[0].bias, p[2].weight, p[2].bias), proj):
+            dst.copy_(src)
+    # dropout noise drawn on the host from the CPU generator exactly like F.dropout does in the reference
+    ts.model._get_engine().dropout_noise = lambda shape: torch.empty(shape, dtype=dt).bernoulli_(0.9)
+    return ts, state, proj
+
+
+def test_deeplab_step_matches_reference_golden(emu, golden_dir):
+    g = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.npz"), allow_pickle=False)
+    b = 2
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, 128, 256, seed=51, two_crops=True, cell=32)
+    ts, _, _ = build(cw=cw)
+    s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+    torch.manual_seed(321)
+    out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
+    # fp32 resolution of this 101-layer fixture: the reference's own fp32 and fp64 forwards differ by 2e-3 (logits)
+    # and 7e-4 (layer4 features) relative to max, so fp32-vs-fp32 comparisons use 1e-2 / 5e-3; exactness of the
+    # graph wiring is pinned at 1e-7 in float64 by the next test.
+    for k in ("total", "supcon", "pixel", "seg"):
+        assert abs(float(out[k].detach()) - float(g[k])) <= 5e-3 * abs(float(g[k])), (k, float(out[k].detach()), float(g[k]))
+    np.testing.assert_allclose(out["left_seg_beforeup"].detach().numpy(), g["before"], rtol=0, atol=1e-2 * np.abs(g["before"]).max())
+    ff = out["fine_feat"].detach().numpy()
+    np.testing.assert_allclose(ff[:, ::8], g["fine_feat_sub"], rtol=0, atol=5e-3 * np.abs(g["fine_feat_sub"]).max())
+    params = dict(ts.model.named_parameters())
+    for k, n in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
+        gn = float(params[k].grad.norm())
+        assert abs(gn - n) <= 5e-2 * max(n, 1e-6) + 1e-7, (k, gn, n)
+
+
+def test_deeplab_engine_matches_oracle_fp64_odd_size(emu):
+    dt = torch.float64
+    b, h, w = 2, 104, 168
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=61, two_crops=True, cell=16)
+    ts, state, proj = build(dt, flat=False, b=b, cw=cw.to(dt))
+    s0 = dict(left=img[:b].to(dt), label=labels.clone(), weather=weather, label_distance_weight=ldw.to(dt))
+    torch.manual_seed(5)
+    out = ts.step((s0, dict(left=img[b:].to(dt))), do_optimizer_step=False)
+    ref, grads, gproj = oracle_deeplab_step(state, proj, img.to(dt), labels.clone(), ldw.to(dt), weather, cw.to(dt), b, 5)
+    assert abs(float(out["total"]) - float(ref["total"])) < 1e-9 * abs(float(ref["total"]))
+    np.testing.assert_allclose(out["fine_feat"].detach().numpy(), ref["fine_feat"].numpy(), rtol=0, atol=1e-9)
+    np.testing.assert_allclose(out["left_seg"].detach().numpy(), ref["seg_logits"].numpy(), rtol=0, atol=1e-9)
+    params = dict(ts.model.named_parameters())
+    for k, gref in grads.items():
+        err = float((params[k].grad - gref).abs().max()) / max(float(gref.abs().max()), 1e-12)
+        assert err < 1e-7, (k, err)
+    sd = ts.model.state_dict()
+    for k, v in state.items():
+        if "running_" in k:
+            assert float((sd[k] - v).abs().max()) < 1e-9, k
+        if "num_batches" in k:
+            assert int(sd[k]) == int(v), k

@@ -344,3 +344,73 @@ def test_adam_and_small_helpers(ops):
 def test_ops_refuse_cpu_tensors(ops):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.conv_fwd(torch.zeros(1, 4, 4, 64), cl(torch.zeros(64, 64, 3, 3)), 1, 1)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,s,dil", [(1, 12, 14, 64, 64, 1, 2), (2, 9, 11, 128, 256, 1, 6), (1, 20, 24, 64, 128, 2, 1),
+                                                  (1, 8, 16, 256, 64, 1, 12)])
+def test_dilated_conv(ops, N, H, W, Cin, Cout, s, dil):
+    x = rnd(N, H, W, Cin, seed=60)
+    w = cl(rnd(Cout, Cin, 3, 3, seed=61, scale=0.05))
+    y_ref = E.conv_fwd(x, w, s, dil, dil=dil)
+    close(ops.conv_fwd(x.to(DEV), cl(w.to(DEV)), s, dil, dil=dil), y_ref, what="dilated fwd")
+    dy = rnd(*y_ref.shape, seed=62)
+    gx = ops.conv_dgrad(dy.to(DEV), ops.pack_dgrad_weight(cl(w.to(DEV))), (H, W), s, dil, dil=dil)
+    close(gx, E.conv_dgrad(dy, E.pack_dgrad_weight(w), (H, W), s, dil, dil=dil), what="dilated dgrad")
+    dw = torch.empty_like(cl(w.to(DEV)))
+    ops.conv_wgrad(x.to(DEV), dy.to(DEV), dw, s, dil, False, dil=dil)
+    dref = torch.empty_like(w)
+    E.conv_wgrad(x, dy, dref, s, dil, False, dil=dil)
+    close(dw, dref, 5e-5, "dilated wgrad")
+
+
+@pytest.mark.parametrize("k,W", [(1, 10), (3, 32), (3, 13)])
+def test_virtual_concat_convolution(ops, k, W):
+    """conv(cat([a, b], C)) == conv(a, w[:, :48]) + conv(b, w[:, 48:]) with slices of ONE weight tensor."""
+    N, H, Ca, Cb, Cout = 2, 6, 48, 256, 64
+    a, b = rnd(N, H, W, Ca, seed=63), rnd(N, H, W, Cb, seed=64)
+    w = cl(rnd(Cout, Ca + Cb, k, k, seed=65, scale=0.05))
+    pad = k // 2
+    ref = E.conv_fwd(torch.cat([a, b], -1), w, 1, pad)
+    wd = cl(w.to(DEV))
+    y = ops.conv_fwd(a.to(DEV), wd, 1, pad, koff=0)
+    ops.conv_fwd(b.to(DEV), wd, 1, pad, koff=Ca, out=y)
+    close(y, ref, what="sliced fwd")
+    dy = rnd(*ref.shape, seed=66)
+    gref = E.conv_dgrad(dy, E.pack_dgrad_weight(w), (H, W), 1, pad)
+    close(ops.conv_dgrad(dy.to(DEV), ops.pack_dgrad_weight(wd, 0, Ca), (H, W), 1, pad), gref[..., :Ca], what="sliced dgrad a")
+    close(ops.conv_dgrad(dy.to(DEV), ops.pack_dgrad_weight(wd, Ca, Cb), (H, W), 1, pad), gref[..., Ca:], what="sliced dgrad b")
+    dw = torch.full_like(wd, 7.0)
+    ops.conv_wgrad(a.to(DEV), dy.to(DEV), dw, 1, pad, False, koff=0)
+    ops.conv_wgrad(b.to(DEV), dy.to(DEV), dw, 1, pad, False, koff=Ca)
+    dref = torch.empty_like(w)
+    E.conv_wgrad(torch.cat([a, b], -1), dy, dref, 1, pad, False)
+    close(dw, dref, 5e-5, "sliced wgrad")
+
+
+def test_dropout(ops):
+    x = rnd(4, 8, 16, 256, seed=67)
+    noise = (torch.from_numpy(np.random.default_rng(68).random(x.shape).astype(np.float32)) < 0.9).float()
+    out, mask = ops.dropout(x.to(DEV), 0.1, noise.to(DEV))
+    close(out, x * noise / 0.9, 1e-6, "dropout with host noise")
+    assert torch.equal(mask.cpu(), noise.to(torch.uint8))
+    g = rnd(*x.shape, seed=69)
+    close(ops.dropout_bwd(g.to(DEV), mask, 0.1), g * noise / 0.9, 1e-6, "dropout bwd")
+    out2, mask2 = ops.dropout(x.to(DEV), 0.1, None, seed=5)
+    keep = float(mask2.float().mean())
+    assert 0.88 < keep < 0.92, keep
+    close(out2, x * mask2.cpu().float() / 0.9, 1e-6, "dropout with device mask")
+    _, mask3 = ops.dropout(x.to(DEV), 0.1, None, seed=6)
+    assert not torch.equal(mask2, mask3)
+
+
+def test_wide_channel_batchnorm_reductions(ops):
+    C, rows = 2048, 300
+    y = rnd(rows, C, seed=70) + 0.3
+    close(ops.colsum(y.to(DEV)), E.colsum(y), 1e-5, "colsum C=2048")
+    gamma, beta = rnd(C, seed=71) * 0.1 + 1, rnd(C, seed=72) * 0.1
+    bn_ref = E.bn_finalize(E.colsum(y), gamma, beta, torch.zeros(C), torch.ones(C), rows, True)
+    g = rnd(rows, C, seed=73)
+    dg_r, db_r, dg, db = torch.zeros(C), torch.zeros(C), torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+    dy_r, _ = E.bn_bwd(g, y, bn_ref, gamma, relu=True, dgamma=dg_r, dbeta=db_r)
+    dy, _ = ops.bn_bwd(g.to(DEV), y.to(DEV), bn_ref.to(DEV), gamma.to(DEV), relu=True, dgamma=dg, dbeta=db)
+    close(dy, dy_r, 2e-5, "bn_bwd C=2048"); close(dg, dg_r, 2e-5, "dgamma C=2048")
