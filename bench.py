@@ -41,6 +41,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--criterion", default="supcon_pixelcontrast_focal")
+    ap.add_argument("--model", default="resnet18", help="resnet18 (SwiftNet pyramid, C3/C4) or deeplabv3plus_resnet101 (C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--conv-report", default=None, help="write a per-shape conv timing table (json lines) to this file")
@@ -138,7 +139,8 @@ def pmc_traffic(args, world):
     """HBM bytes per conv_gather launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
     path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_c3.json")
-    default = (args.batch, args.height, args.width, args.criterion) == (16, 1024, 2048, "supcon_pixelcontrast_focal")
+    default = (args.batch, args.height, args.width, args.criterion, args.model) == \
+        (16, 1024, 2048, "supcon_pixelcontrast_focal", "resnet18")
     if not (default and os.path.exists(path)):
         return None
     with open(path) as f:
@@ -166,7 +168,9 @@ def main():
     b = args.batch
     left0, left1, labels, ldw, weather, cw = device_batch(O, b, args.height, args.width, 1000 * rank, two, dev)
     torch.manual_seed(1)
-    ts = TrainStep(make_opts(criterion=args.criterion, batch_size=b * world), class_weight=cw, device=dev)
+    deeplab = args.model.startswith("deeplab")
+    ts = TrainStep(make_opts(criterion=args.criterion, batch_size=b * world, model=args.model, deeplab=deeplab),
+                   class_weight=cw, device=dev)
     if world > 1:
         from dcs_amd.dist import DataParallelStep
         stepper = DataParallelStep(ts, rank, world)
@@ -217,11 +221,13 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C3: SwiftNet-RN18 pyramid + {args.criterion}, B={b}/GPU labelled images x {crops} crops "
+            "config": {"workload": (f"C5: DeepLabV3+ RN101 (OS16)" if deeplab else "C3: SwiftNet-RN18 pyramid") +
+                                   f" + {args.criterion}, B={b}/GPU labelled images x {crops} crops "
                                    f"at {args.width}x{args.height}, fwd+losses+bwd+Adam",
                        "global_batch": b * world, "crops_per_image": crops, "parallelism": f"dp{world}",
                        "model_images_per_sec": value * crops,
-                       "conv_tflops_per_gpu_whole_step": value * crops * 769.2e9 * (args.height * args.width / (1024 * 2048)) / 1e12 / world,
+                       "conv_tflops_per_gpu_whole_step": value * crops * (3 * 2 * 631.6e9 if deeplab else 769.2e9) *
+                                                         (args.height * args.width / (1024 * 2048)) / 1e12 / world,
                        "final_loss": loss},
             "roofline": {"bound": "mfma", "achieved": g["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": g["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(args, world),

@@ -171,6 +171,8 @@ class DeepLabEngine:
             branches.append((conv, bnm, yb, bnb, zb))
         pconv, pbn = asp.convs[4][1], asp.convs[4][2]
         pooled = ops.colsum(f.reshape(B * hf * wf, f.shape[-1]), B=B, scale=1.0 / (hf * wf))[:, 0, :].contiguous()
+        if training and B == 1:              # same error as nn.BatchNorm2d on a [1,256,1,1] input (torch/nn/functional.py)
+            raise ValueError(f"Expected more than 1 value per channel when training, got input size {(B, 256, 1, 1)}")
         yp = ops.linear(pooled, pconv.weight.reshape(pconv.weight.shape[0], -1))
         bnp = self._bn(yp, pbn, training, rows=B)
         zp = ops.bn_act(yp, bnp, relu=True)                                    # [B,256]
