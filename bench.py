@@ -152,13 +152,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("DCS_SHARE_GPU"):                          # rehearsal: several ranks on one GPU (gloo only)
+        local = 0
     if args.gpus > 1 and world == 1:
         raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("DCS_DIST_BACKEND", "nccl")      # "nccl" = RCCL; "gloo" only for single-GPU rehearsals
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import dcs_amd.ops as ops
     from dcs_amd.trainer import TrainStep, make_opts
