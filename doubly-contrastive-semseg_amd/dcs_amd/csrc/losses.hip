@@ -287,6 +287,64 @@ __global__ void symmetrize_kernel(const float* __restrict__ G, float* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// validation: per-pixel class id (argmax of the logits, optionally of the bilinearly upsampled low-resolution
+// logits so the full-resolution tensor is never materialised) + confusion matrix, fused
+// (trainer.py:349 + metrics/stream_metrics.py:330-342).  Integer LDS histogram per block, integer global atomics.
+struct LinC { int i0, i1; float w0, w1; };
+__device__ __forceinline__ LinC linc(int o, float scale, int in) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  LinC l;
+  l.i0 = (int)s;
+  if (l.i0 > in - 1) l.i0 = in - 1;
+  l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+  l.w1 = s - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+
+template <bool LOWRES>
+__global__ __launch_bounds__(256)
+void confusion_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                      unsigned char* __restrict__ pred_out, unsigned long long* __restrict__ conf, int C, int H, int W,
+                      int ih, int iw, int cs) {
+  extern __shared__ int hist[];                       // [C*C]
+  const int n = blockIdx.y;
+  const long long HW = (long long)H * W;
+  for (int t = threadIdx.x; t < C * C; t += 256) hist[t] = 0;
+  __syncthreads();
+  const float sy = (float)ih / (float)H, sx = (float)iw / (float)W;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long long)gridDim.x * 256) {
+    int best = 0;
+    float bv = -INFINITY;
+    if (!LOWRES) {
+      const float* lp = logits + (long long)n * C * HW + p;
+      for (int c = 0; c < C; ++c) { const float v = lp[(long long)c * HW]; if (v > bv) { bv = v; best = c; } }
+    } else {
+      const int oy = (int)(p / W), ox = (int)(p - (long long)oy * W);
+      const LinC ly = linc(oy, sy, ih), lx = linc(ox, sx, iw);
+      const float* b = logits + (long long)n * ih * iw * cs;
+      const float* p00 = b + ((long long)ly.i0 * iw + lx.i0) * cs;
+      const float* p01 = b + ((long long)ly.i0 * iw + lx.i1) * cs;
+      const float* p10 = b + ((long long)ly.i1 * iw + lx.i0) * cs;
+      const float* p11 = b + ((long long)ly.i1 * iw + lx.i1) * cs;
+      for (int c = 0; c < C; ++c) {
+        const float top = fmaf(lx.w1, p01[c], lx.w0 * p00[c]);
+        const float bot = fmaf(lx.w1, p11[c], lx.w0 * p10[c]);
+        const float v = fmaf(ly.w1, bot, ly.w0 * top);           // same arithmetic as upsample_to_nchw_kernel
+        if (v > bv) { bv = v; best = c; }
+      }
+    }
+    if (pred_out) pred_out[(long long)n * HW + p] = (unsigned char)best;
+    const long long gt = labels[(long long)n * HW + p];
+    if (gt >= 0 && gt < C) atomicAdd(&hist[(int)gt * C + best], 1);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < C * C; t += 256)
+    if (hist[t]) atomicAdd(&conf[(long long)n * C * C + t], (unsigned long long)hist[t]);
+}
+
 inline unsigned grid_for(long long n, unsigned cap = 8192) {
   long long b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -360,5 +418,23 @@ extern "C" int dcs_contrast_rows(const float* S, const float* labels, float* los
 extern "C" int dcs_symmetrize(const float* G, float* Gs, int A, int ld, void* stream) {
   DCS_CHECK_ARG(G && Gs && A > 0 && ld >= A);
   hipLaunchKernelGGL(symmetrize_kernel, dim3(grid_for((long long)A * ld)), dim3(256), 0, dcs_stream(stream), G, Gs, A, ld);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_confusion(const float* logits, const int64_t* labels, uint8_t* pred_out, uint64_t* conf, int N, int C,
+                             int H, int W, int lowres_h, int lowres_w, int cs, void* stream) {
+  DCS_CHECK_ARG(logits && labels && conf && N > 0 && C > 0 && C <= 64 && H > 0 && W > 0);
+  DCS_CHECK_ARG((lowres_h == 0 && lowres_w == 0) || (lowres_h > 0 && lowres_w > 0 && cs >= C));
+  const long long HW = (long long)H * W;
+  long long bx = (HW + 255) / 256;
+  if (bx > 2048) bx = 2048;
+  dim3 grid((unsigned)bx, (unsigned)N);
+  const size_t sh = (size_t)C * C * sizeof(int);
+  if (lowres_h == 0)
+    hipLaunchKernelGGL(confusion_kernel<false>, grid, dim3(256), sh, dcs_stream(stream), logits, labels, pred_out,
+                       (unsigned long long*)conf, C, H, W, 0, 0, 0);
+  else
+    hipLaunchKernelGGL(confusion_kernel<true>, grid, dim3(256), sh, dcs_stream(stream), logits, labels, pred_out,
+                       (unsigned long long*)conf, C, H, W, lowres_h, lowres_w, cs);
   DCS_LAUNCH_RET();
 }

@@ -570,6 +570,24 @@ def dropout_bwd(g, mask, p):
     return out
 
 
+def confusion(logits, labels, num_classes, conf, lowres=None, want_pred=False):
+    """conf [N,C,C] int64 (device) += confusion of argmax(logits) vs labels.  logits: NCHW full-resolution tensor, or,
+    with lowres=(H, W), the low-resolution NHWC logits buffer that is upsampled on the fly to HxW."""
+    N = labels.shape[0]
+    H, W = labels.shape[1:]
+    if labels.dtype != torch.int64 or not labels.is_contiguous() or not labels.is_cuda:
+        raise RuntimeError("confusion: labels must be a contiguous int64 device tensor (no CPU fallback)")
+    pred = torch.empty((N, H, W), device=labels.device, dtype=torch.uint8) if want_pred else None
+    if lowres is None:
+        _req(logits)
+        _call("dcs_confusion", _p(logits), _p(labels), _p(pred), _p(conf), N, num_classes, H, W, 0, 0, 0, _stream())
+    else:
+        _req(logits)
+        _, ih, iw, cs = logits.shape
+        _call("dcs_confusion", _p(logits), _p(labels), _p(pred), _p(conf), N, num_classes, H, W, ih, iw, cs, _stream())
+    return pred
+
+
 def sum_scalar(x, scale=1.0):
     out = torch.empty((1,), device=x.device, dtype=_F32)
     _call("dcs_sum_scalar", _p(_req(x)), _p(out), x.numel(), float(scale), _stream())

@@ -172,6 +172,15 @@ int dcs_anchor_select(const uint8_t* key, const int32_t* hist, const int32_t* re
 int dcs_gather_rows(const float* feat, const int32_t* rowidx, float* X, int A, int C, void* stream);
 int dcs_scatter_add_rows(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, void* stream);
 
+/* ---- validation: class-id argmax + confusion matrix (trainer.py:349, metrics/stream_metrics.py:330-342) --------
+ * conf[n][gt][pred] (uint64, one C x C matrix per image, += ) over pixels with 0 <= gt < C; pred = argmax_c (first max).
+ * lowres_h == 0: logits is the full-resolution NCHW tensor [N,C,H,W].
+ * lowres_h  > 0: logits is the low-resolution NHWC tensor [N,lowres_h,lowres_w,cs] and is bilinearly upsampled
+ *               (align_corners=False) to HxW on the fly -- the 2.55 GB full-resolution logits never exist.
+ * pred_out (nullable): uint8 class ids [N,H,W]. */
+int dcs_confusion(const float* logits, const int64_t* labels, uint8_t* pred_out, uint64_t* conf, int N, int C, int H,
+                  int W, int lowres_h, int lowres_w, int cs, void* stream);
+
 /* ---- contrastive rows (utils/loss.py:175-204 and :361-386) -----------------------------------
  * S [A,ld] = C C^T (from dcs_conv_gather in 1x1 mode), scaled by inv_temp = 1/T on read.  For every row i < A:
  *   max-subtract, L2-normalise, masked exp/log reductions; loss_row[i]; G[i][j] = d(mean loss)/dS_ij

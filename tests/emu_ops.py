@@ -351,6 +351,17 @@ def dropout_bwd(g, mask, p):
     return g * mask.to(g.dtype) / (1 - p)
 
 
+def confusion(logits, labels, num_classes, conf, lowres=None, want_pred=False):
+    if lowres is not None:
+        logits = upsample_to_nchw(logits, num_classes, labels.shape[1], labels.shape[2])
+    pred = logits.argmax(1)
+    for n in range(labels.shape[0]):
+        m = (labels[n] >= 0) & (labels[n] < num_classes)
+        idx = num_classes * labels[n][m] + pred[n][m]
+        conf[n] += torch.bincount(idx, minlength=num_classes ** 2).reshape(num_classes, num_classes)
+    return pred.to(torch.uint8) if want_pred else None
+
+
 def sum_scalar(x, scale=1.0):
     return (x.double().sum() * scale).to(x.dtype).reshape(1)
 
