@@ -71,27 +71,36 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
   }
 }
 
-// out[b][2][C] = scale * sum_g partial[b][g][2][C].  Block = 32 output columns x 8 group lanes; each lane sums
-// groups gl, gl+8, ... in double, then the 8 lanes are added in fixed order (deterministic).
+// out[b][2][C] = scale * sum_g partial[b][g][2][C].  Block = 8 float4 columns x 32 group lanes; each lane sums
+// groups gl, gl+32, ... in double (independent 16-B loads, unrolled), then the 32 lanes are added in fixed order.
 __global__ __launch_bounds__(256)
 void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int groups, int C,
                                     float scale) {
-  __shared__ double sm[8][33];
+  __shared__ double sm[32][8][4];
   const int b = blockIdx.y;
-  const int col = blockIdx.x * 32 + (threadIdx.x & 31);
-  const int gl = threadIdx.x >> 5;
-  double s = 0.0;
+  const int cl = threadIdx.x & 7, gl = threadIdx.x >> 3;
+  const int col = (blockIdx.x * 8 + cl) * 4;
+  const long long ld = 2ll * C;
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (col < 2 * C) {
-    const float* p = partial + (long long)b * groups * 2 * C + col;
-    for (int gi = gl; gi < groups; gi += 8) s += (double)p[(long long)gi * 2 * C];
+    const float* p = partial + (long long)b * groups * ld + col;
+#pragma unroll 4
+    for (int gi = gl; gi < groups; gi += 32) {
+      const float4 v = ld4(p + (long long)gi * ld);
+      s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+    }
   }
-  sm[gl][threadIdx.x & 31] = s;
+  sm[gl][cl][0] = s0; sm[gl][cl][1] = s1; sm[gl][cl][2] = s2; sm[gl][cl][3] = s3;
   __syncthreads();
-  if (gl == 0 && col < 2 * C) {
-    double t = 0.0;
+  if (threadIdx.x < 32) {
+    const int c8 = threadIdx.x >> 2, j = threadIdx.x & 3;
+    const int oc = (blockIdx.x * 8 + c8) * 4 + j;
+    if (oc < 2 * C) {
+      double t = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) t += sm[k][threadIdx.x];
-    out[(long long)b * 2 * C + col] = (float)(t * (double)scale);
+      for (int k = 0; k < 32; ++k) t += sm[k][c8][j];
+      out[(long long)b * ld + oc] = (float)(t * (double)scale);
+    }
   }
 }
 
@@ -228,13 +237,13 @@ __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, 
 }
 
 __global__ void add_rowvec_bcast_kernel(float* __restrict__ g, const float* __restrict__ v, long long HW, int C,
-                                        float scale, long long n4) {
+                                        float scale, long long n4, int accumulate) {
   const int C4 = C >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     const long long n = i / (HW * C4);
     const float4 a = ld4(v + n * C + c);
-    float4 o = ld4(g + i * 4);
+    float4 o = accumulate ? ld4(g + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
     o.x = fmaf(scale, a.x, o.x); o.y = fmaf(scale, a.y, o.y); o.z = fmaf(scale, a.z, o.z); o.w = fmaf(scale, a.w, o.w);
     st4(g + i * 4, o);
   }
@@ -326,7 +335,7 @@ extern "C" int dcs_colsum_partial(const float* x, const float* y, const float* m
 }
 
 extern "C" int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale, void* stream) {
-  DCS_CHECK_ARG(partial && out && B > 0 && groups > 0 && C > 0);
+  DCS_CHECK_ARG(partial && out && B > 0 && groups > 0 && C > 0 && (C & 1) == 0 && dcs_aligned16(partial));
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((2 * C + 31) / 32), (unsigned)B), dim3(256), 0, dcs_stream(stream),
                      partial, out, groups, C, scale);
   DCS_LAUNCH_RET();
@@ -382,11 +391,12 @@ extern "C" int dcs_axpy(float* y, const float* x, int64_t n, float a, void* stre
   DCS_LAUNCH_RET();
 }
 
-extern "C" int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW, int C, float scale, void* stream) {
+extern "C" int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW, int C, float scale, int accumulate,
+                                    void* stream) {
   DCS_CHECK_ARG(g && v && N > 0 && HW > 0 && C > 0 && (C & 3) == 0);
   const long long n4 = (long long)N * HW * (C / 4);
   hipLaunchKernelGGL(add_rowvec_bcast_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, v, (long long)HW, C,
-                     scale, n4);
+                     scale, n4, accumulate);
   DCS_LAUNCH_RET();
 }
 

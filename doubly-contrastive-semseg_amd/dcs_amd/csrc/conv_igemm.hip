@@ -56,8 +56,10 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   constexpr int NG = BKT / 8;            // MFMA k8 groups per chunk
   static_assert(BROWS >= 1 && (NG == 4 || NG == 2), "unsupported tile");
 
-  __shared__ __attribute__((aligned(16))) float As[2][BM * LDKT];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDKT];
+  // one array: As[2][BM*LDKT] followed by Bs[2][BN*LDKT]; the epilogue reuses it as per-wave staging tiles
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDKT];
+  float (*As)[BM * LDKT] = reinterpret_cast<float (*)[BM * LDKT]>(smem);
+  float (*Bs)[BN * LDKT] = reinterpret_cast<float (*)[BN * LDKT]>(smem + 2 * BM * LDKT);
   __shared__ long long rowoff[BM];
   __shared__ int s_oy[DCS_MAX_TAPS], s_ox[DCS_MAX_TAPS], s_wo[DCS_MAX_TAPS], s_to[DCS_MAX_TAPS];
 
@@ -227,39 +229,70 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   }
 
   // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+  // Each wave transposes its accumulators 32 rows at a time through a private LDS tile and writes 16 B per lane
+  // (a quarter wave covers one contiguous run of the pixel's channels) instead of 4-byte column-strided stores.
   // With `stats`, the per-channel sum and sum of squares of this block's outputs (the BatchNorm batch statistics
   // of the layer that follows) are reduced here in fixed order and written to stats[mtile][2][Cout], so the
   // activation is not read again by a separate reduction pass.
-  float* st = &As[0][0];                 // [WM][BN][2] scratch, free after the final barrier of the main loop
+  constexpr int EPC = TN * 32;            // columns of a wave's sub-tile
+  constexpr int EPL = EPC + 4;            // staging row stride (16-B aligned rows, conflict-free column writes)
+  constexpr int EPV = EPC / 4;            // float4 per staged row
+  constexpr int EPR = 64 / EPV;           // rows per read-back pass
+  static_assert(4 * 32 * EPL + WM * BN * 2 <= 2 * (BM + BN) * LDKT, "staging does not fit");
+  float* stg = smem + wid * (32 * EPL);
+  float* st = smem + 4 * 32 * EPL;        // [WM][BN][2] statistics scratch
+  const bool vec_ok = (g.dst_cstride & 3) == 0 && (reinterpret_cast<unsigned long long>(dst) & 15ull) == 0;
+  float ssum[TN], ssq[TN];
 #pragma unroll
-  for (int b = 0; b < TN; ++b) {
-    const int cl = wn * TN * 32 + b * 32 + l31;
-    const int col = co0 + cl;
-    float ssum = 0.f, ssq = 0.f;
-    if (col < g.Cout) {
-      const float bv = bias ? bias[col] : 0.f;
+  for (int b = 0; b < TN; ++b) { ssum[b] = 0.f; ssq[b] = 0.f; }
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+  for (int a = 0; a < TM; ++a) {
+    const int row0 = wm * TM * 32 + a * 32;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = wm * TM * 32 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const long long ro = rowoff[row];
-          if (ro < 0) continue;
-          float* p = dst + ro + col;
-          float v = acc[a][b][r] + bv;
-          if (accumulate) v += *p;
-          *p = v;
-          ssum += v;
-          ssq = fmaf(v, v, ssq);
-        }
+    for (int b = 0; b < TN; ++b) {
+      const int col = co0 + wn * EPC + b * 32 + l31;
+      const float bvv = (bias && col < g.Cout) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[a][b][r] + bvv;
+        stg[rl * EPL + b * 32 + l31] = v;
+        if (stats && rowoff[row0 + rl] >= 0) { ssum[b] += v; ssq[b] = fmaf(v, v, ssq[b]); }
+      }
     }
-    if (stats) {
-      ssum += __shfl_xor(ssum, 32, 64);
-      ssq += __shfl_xor(ssq, 32, 64);
-      if (h == 0) { st[(wm * BN + cl) * 2] = ssum; st[(wm * BN + cl) * 2 + 1] = ssq; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int c4 = lane % EPV, rr = lane / EPV;
+    const int colv = co0 + wn * EPC + c4 * 4;
+#pragma unroll
+    for (int p = 0; p < 32 / EPR; ++p) {
+      const int rl = p * EPR + rr;
+      const long long ro = rowoff[row0 + rl];
+      if (ro < 0 || colv >= g.Cout) continue;
+      float4 v = ld4(&stg[rl * EPL + c4 * 4]);
+      float* q = dst + ro + colv;
+      if (vec_ok && colv + 3 < g.Cout) {
+        if (accumulate) { const float4 o = ld4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *reinterpret_cast<float4*>(q) = v;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (colv + e < g.Cout) q[e] = accumulate ? q[e] + vv[e] : vv[e];
+      }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   if (stats) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int cl = wn * EPC + b * 32 + l31;
+      float s0 = ssum[b], s1 = ssq[b];
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (h == 0) { st[(wm * BN + cl) * 2] = s0; st[(wm * BN + cl) * 2 + 1] = s1; }
+    }
     __syncthreads();
     if (tid < BN && co0 + tid < g.Cout) {
       float s0 = 0.f, s1 = 0.f;
@@ -840,13 +873,17 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   const int ntiles = (geom->Cout + bn - 1) / bn;
   const long long blocks = mtiles * ntiles;
   DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
+  DCS_CHECK_ARG(!(stats && accumulate));
+  // few K chunks per tile (1x1 convolutions up to 512 channels): 16-channel chunks, 3 blocks per CU, so that the
+  // prologue / epilogue of one tile overlaps the main loop of two others (measured +14..18 % on those shapes)
+  const bool short_k = (long long)geom->ntaps * ((geom->K + 31) / 32) <= 16;
   hipStream_t s = dcs_stream(stream);
 #define LAUNCH_GATHER(B)                                                                                              \
   do {                                                                                                                \
     if (geom->stem)                                                                                                   \
       hipLaunchKernelGGL((conv_gather_kernel<B, true, 32>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias,  \
                          dst, *geom, accumulate, ntiles, stats);                                                      \
-    else if (B == 64 || (B == 128 && g_bk16))                                                                         \
+    else if (B == 64 || (B == 128 && (g_bk16 || short_k)))                                                                       \
       hipLaunchKernelGGL((conv_gather_kernel<(B >= 64 ? B : 64), false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, \
                          src, wgt, bias, dst, *geom, accumulate, ntiles, stats);                                      \
     else                                                                                                              \

@@ -130,6 +130,125 @@ void maxpool_bwd_kernel(const float* __restrict__ g, const uint8_t* __restrict__
   }
 }
 
+// ---- stem backward without the pooled-gradient tensor ------------------------------------------------
+// d(loss)/d(relu output) of the 2x2 pixel quad (2qy..2qy+1, 2qx..2qx+1) from the pooled gradient: the quad is touched
+// by exactly the four windows (qy..qy+1, qx..qx+1), so one thread gathers 4 x (float4 + uchar4) for 4 pixels.
+// Window slot k = ky*3+kx of the forward kernel; additions in the same (ky, kx) order as maxpool_bwd_kernel.
+__device__ __forceinline__ void pool_quad_grad(const float* __restrict__ g, const uint8_t* __restrict__ idx, int n, int qy,
+                                               int qx, int c, int OH, int OW, int C, float4 out[4]) {
+  float4 gv[4];
+  uchar4 id[4];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    const int oy = qy + (w >> 1), ox = qx + (w & 1);
+    if (oy < OH && ox < OW) {
+      const long long o = (((long long)n * OH + oy) * OW + ox) * C + c;
+      gv[w] = ld4(g + o);
+      id[w] = *reinterpret_cast<const uchar4*>(idx + o);
+    } else {
+      gv[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+      id[w] = make_uchar4(255, 255, 255, 255);
+    }
+  }
+#define DCS_PICK(WI, K) make_float4(id[WI].x == (K) ? gv[WI].x : 0.f, id[WI].y == (K) ? gv[WI].y : 0.f,                \
+                                    id[WI].z == (K) ? gv[WI].z : 0.f, id[WI].w == (K) ? gv[WI].w : 0.f)
+  out[0] = DCS_PICK(0, 4);
+  out[1] = f4add(DCS_PICK(1, 3), DCS_PICK(0, 5));
+  out[2] = f4add(DCS_PICK(2, 1), DCS_PICK(0, 7));
+  out[3] = f4add(f4add(f4add(DCS_PICK(3, 0), DCS_PICK(2, 2)), DCS_PICK(1, 6)), DCS_PICK(0, 8));
+#undef DCS_PICK
+}
+
+// partial[group][2][C]: sum of the masked gradient and of gradient * xhat over the group's quads
+__global__ __launch_bounds__(256)
+void bn_pool_bwd_partial_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                                const float* __restrict__ bn, float* __restrict__ partial, int N, int H, int W, int OH,
+                                int OW, int C, int groups) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][RL][C]
+  const int C4 = C >> 2, RL = 256 / C4;
+  const int tid = threadIdx.x, col4 = tid % C4, rl = tid / C4;
+  const int c = col4 * 4;
+  const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+  const long long Q = (long long)N * QH * QW;
+  const long long qpg = (Q + groups - 1) / groups;
+  const long long qbeg = (long long)blockIdx.x * qpg;
+  const long long qend = qbeg + qpg < Q ? qbeg + qpg : Q;
+  const float4 sc = ld4(bn + c), sh = ld4(bn + C + c), mu = ld4(bn + 2 * C + c), is = ld4(bn + 3 * C + c);
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  for (long long q = qbeg + rl; q < qend; q += RL) {
+    const int qx = (int)(q % QW);
+    const long long t = q / QW;
+    const int qy = (int)(t % QH), n = (int)(t / QH);
+    float4 gq[4];
+    pool_quad_grad(g, idx, n, qy, qx, c, OH, OW, C, gq);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int iy = 2 * qy + (p >> 1), ix = 2 * qx + (p & 1);
+      if (iy >= H || ix >= W) continue;
+      const float4 yy = ld4(y + (((long long)n * H + iy) * W + ix) * C + c);
+      float4 v = gq[p];
+      v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
+      v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
+      s0 = f4add(s0, v);
+      s1.x = fmaf(v.x, (yy.x - mu.x) * is.x, s1.x); s1.y = fmaf(v.y, (yy.y - mu.y) * is.y, s1.y);
+      s1.z = fmaf(v.z, (yy.z - mu.z) * is.z, s1.z); s1.w = fmaf(v.w, (yy.w - mu.w) * is.w, s1.w);
+    }
+  }
+  st4(&sm[(0 * RL + rl) * C + c], s0);
+  st4(&sm[(1 * RL + rl) * C + c], s1);
+  __syncthreads();
+  for (int t = tid; t < 2 * C; t += 256) {
+    const int which = t / C, cc = t - which * C;
+    float s = 0.f;
+    for (int k = 0; k < RL; ++k) s += sm[(which * RL + k) * C + cc];
+    partial[((long long)blockIdx.x * 2 + which) * C + cc] = s;
+  }
+}
+
+__global__ __launch_bounds__(256)
+void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, const float* __restrict__ y,
+                              const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
+                              float* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int H,
+                              int W, int OH, int OW, int C, int acc_param, int training) {
+  const int C4 = C >> 2;
+  const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
+  const long long total = (long long)N * QH * QW * C4;
+  const float inv = training ? (float)(1.0 / ((double)N * H * W)) : 0.f;
+  if (blockIdx.x == 0 && dgamma) {
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+      dbeta[c] = (acc_param ? dbeta[c] : 0.f) + sums[c];
+      dgamma[c] = (acc_param ? dgamma[c] : 0.f) + sums[C + c];
+    }
+  }
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    long long q = i / C4;
+    const int qx = (int)(q % QW); q /= QW;
+    const int qy = (int)(q % QH);
+    const int n = (int)(q / QH);
+    const float4 sc = ld4(bn + c), sh = ld4(bn + C + c), mu = ld4(bn + 2 * C + c), is = ld4(bn + 3 * C + c);
+    const float4 gw = ld4(gamma + c), s0 = ld4(sums + c), s1 = ld4(sums + C + c);
+    float4 gq[4];
+    pool_quad_grad(g, idx, n, qy, qx, c, OH, OW, C, gq);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int iy = 2 * qy + (p >> 1), ix = 2 * qx + (p & 1);
+      if (iy >= H || ix >= W) continue;
+      const long long off = (((long long)n * H + iy) * W + ix) * C + c;
+      const float4 yy = ld4(y + off);
+      float4 v = gq[p];
+      v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
+      v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
+      float4 o;
+      o.x = gw.x * is.x * (v.x - s0.x * inv - (yy.x - mu.x) * is.x * (s1.x * inv));
+      o.y = gw.y * is.y * (v.y - s0.y * inv - (yy.y - mu.y) * is.y * (s1.y * inv));
+      o.z = gw.z * is.z * (v.z - s0.z * inv - (yy.z - mu.z) * is.z * (s1.z * inv));
+      o.w = gw.w * is.w * (v.w - s0.w * inv - (yy.w - mu.w) * is.w * (s1.w * inv));
+      st4(dy + off, o);
+    }
+  }
+}
+
 // ---- bilinear, align_corners=False, explicit output size (torch area_pixel_compute_source_index) -----
 struct Lin { int i0, i1; float w0, w1; };
 __device__ __forceinline__ Lin lin_src(int o, float scale, int in) {
@@ -281,6 +400,62 @@ void upsample_to_nchw_bwd_kernel(const float* __restrict__ g, const float* __res
   }
 }
 
+// Separable form of the same adjoint (bilinear weights factor into wy * wx): pass 1 folds the X axis of every
+// full-resolution row, r[plane][Y][x] = sum_X wx(X,x) g[plane][Y][X]  (reads g once, coalesced along X);
+// pass 2 folds Y and transposes to NHWC through LDS so the channel-strided rows are written as whole lines.
+__global__ __launch_bounds__(256)
+void upsample_fold_x_kernel(const float* __restrict__ g, float* __restrict__ r, long long planes_rows, int IW, int OW) {
+  const long long total = planes_rows * IW;
+  const float sx = (float)IW / (float)OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int ix = (int)(i % IW);
+    const long long row = i / IW;
+    int xlo, xhi;
+    out_range(ix, sx, OW, xlo, xhi);
+    const float* gp = g + row * OW;
+    float acc = 0.f;
+    for (int ox = xlo; ox <= xhi; ++ox) {
+      const float wx = lin_w(ox, sx, IW, ix);
+      if (wx != 0.f) acc = fmaf(wx, gp[ox], acc);
+    }
+    r[i] = acc;
+  }
+}
+
+constexpr int FOLD_MAXC = 32;
+__global__ __launch_bounds__(256)
+void upsample_fold_y_nhwc_kernel(const float* __restrict__ r, const float* __restrict__ gscale, float* __restrict__ gx,
+                                 int IH, int IW, int cs, int C, int OH) {
+  extern __shared__ float tile[];            // [256][cs]
+  const int n = blockIdx.z, iy = blockIdx.y;
+  const int x0 = blockIdx.x * 256;
+  const int ix = x0 + threadIdx.x;
+  const float sy = (float)IH / (float)OH;
+  const float gs = gscale ? gscale[0] : 1.f;
+  float acc[FOLD_MAXC];
+#pragma unroll
+  for (int c = 0; c < FOLD_MAXC; ++c) acc[c] = 0.f;
+  if (ix < IW) {
+    int ylo, yhi;
+    out_range(iy, sy, OH, ylo, yhi);
+    for (int oy = ylo; oy <= yhi; ++oy) {
+      const float wy = lin_w(oy, sy, IH, iy);
+      if (wy == 0.f) continue;
+      const float* rp = r + (((long long)n * C) * OH + oy) * IW + ix;
+#pragma unroll
+      for (int c = 0; c < FOLD_MAXC; ++c)
+        if (c < C) acc[c] = fmaf(wy, rp[(long long)c * OH * IW], acc[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < FOLD_MAXC; ++c)
+    if (c < cs) tile[threadIdx.x * cs + c] = c < C ? acc[c] * gs : 0.f;
+  __syncthreads();
+  const int nx = IW - x0 < 256 ? IW - x0 : 256;
+  float* o = gx + (((long long)n * IH + iy) * IW + x0) * cs;
+  for (int t = threadIdx.x; t < nx * cs; t += 256) o[t] = tile[t];
+}
+
 inline unsigned grid_for(long long n, unsigned cap = 16384) {
   long long b = (n + 255) / 256;
   if (b < 1) b = 1;
@@ -327,6 +502,29 @@ extern "C" int dcs_maxpool_bwd(const float* g, const uint8_t* idx, float* gz, in
   DCS_LAUNCH_RET();
 }
 
+extern "C" int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const float* y, const float* bn, float* partial,
+                                       int N, int H, int W, int C, int groups, void* stream) {
+  DCS_CHECK_ARG(g && idx && y && bn && partial && N > 0 && H > 0 && W > 0 && groups > 0);
+  DCS_CHECK_ARG(C >= 4 && C <= 1024 && (C & 3) == 0 && 256 % (C / 4) == 0);
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const size_t sh = (size_t)2 * (256 / (C / 4)) * C * sizeof(float);
+  hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3((unsigned)groups), dim3(256), sh, dcs_stream(stream), g, idx, y, bn,
+                     partial, N, H, W, OH, OW, C, groups);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_bn_pool_bwd_apply(const float* g, const uint8_t* idx, const float* y, const float* bn, const float* gamma,
+                                     const float* sums, float* dy, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                                     int acc_param, int training, void* stream) {
+  DCS_CHECK_ARG(g && idx && y && bn && gamma && sums && dy && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
+  DCS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
+  hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), g, idx, y, bn, gamma,
+                     sums, dy, dgamma, dbeta, N, H, W, OH, OW, C, acc_param, training);
+  DCS_LAUNCH_RET();
+}
+
 extern "C" int dcs_upsample_add(const float* x, const float* s0, const float* s1, const float* s2, float* t, int N,
                                 int IH, int IW, int OH, int OW, int C, void* stream) {
   DCS_CHECK_ARG(x && t && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && (C & 3) == 0);
@@ -354,10 +552,19 @@ extern "C" int dcs_upsample_to_nchw(const float* x, float* out, int N, int IH, i
   DCS_LAUNCH_RET();
 }
 
-extern "C" int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, float* gx, int N, int IH, int IW, int cs,
-                                        int C, int OH, int OW, void* stream) {
+extern "C" int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, float* gx, float* tmp, int N, int IH,
+                                        int IW, int cs, int C, int OH, int OW, void* stream) {
   DCS_CHECK_ARG(g && gx && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && cs >= C);
-  hipLaunchKernelGGL(upsample_to_nchw_bwd_kernel, dim3(grid_for((long long)N * cs * IH * IW)), dim3(256), 0,
-                     dcs_stream(stream), g, gscale, gx, N, IH, IW, cs, C, OH, OW);
+  hipStream_t s = dcs_stream(stream);
+  if (tmp && C <= FOLD_MAXC && cs <= 2 * FOLD_MAXC && IH <= 65535 && N <= 65535) {
+    // tmp: [N*C*OH*IW] floats
+    const long long rows = (long long)N * C * OH;
+    hipLaunchKernelGGL(upsample_fold_x_kernel, dim3(grid_for(rows * IW, 1u << 20)), dim3(256), 0, s, g, tmp, rows, IW, OW);
+    hipLaunchKernelGGL(upsample_fold_y_nhwc_kernel, dim3((unsigned)((IW + 255) / 256), (unsigned)IH, (unsigned)N), dim3(256),
+                       (size_t)256 * cs * sizeof(float), s, tmp, gscale, gx, IH, IW, cs, C, OH);
+    DCS_LAUNCH_RET();
+  }
+  hipLaunchKernelGGL(upsample_to_nchw_bwd_kernel, dim3(grid_for((long long)N * cs * IH * IW)), dim3(256), 0, s, g, gscale,
+                     gx, N, IH, IW, cs, C, OH, OW);
   DCS_LAUNCH_RET();
 }

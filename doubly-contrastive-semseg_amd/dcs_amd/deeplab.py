@@ -362,8 +362,10 @@ class DeepLabEngine:
                 g_cur = g_in
             else:
                 _, p0, y, bn, pidx = item
-                gz = ops.maxpool_bwd(g_cur, pidx, y.shape[1], y.shape[2])
-                dy, _ = bn_bwd(self.bb["bn1"], gz, y, bn, relu=True)
+                m1 = self.bb["bn1"]
+                grads[m1.weight], grads[m1.bias] = self._galloc(m1.weight), self._galloc(m1.bias)
+                dy = ops.bn_pool_bwd(g_cur, pidx, y, bn, m1.weight, dgamma=grads[m1.weight], dbeta=grads[m1.bias],
+                                     acc_param=False, training=training)
                 dwst = torch.empty((64, 7, 8, 4), device=dy.device, dtype=dy.dtype)
                 ops.stem_wgrad(p0, dy, dwst, False)
                 w1 = self.bb["conv1"].weight

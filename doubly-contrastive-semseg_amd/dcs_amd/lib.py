@@ -45,10 +45,12 @@ SIGNATURES = {
     "dcs_normalize_pyramid": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "dcs_bn_relu_maxpool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dcs_maxpool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "dcs_bn_pool_bwd_partial": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dcs_bn_pool_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dcs_upsample_add": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dcs_upsample_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_upsample_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dcs_upsample_to_nchw_bwd": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dcs_upsample_to_nchw_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_seg_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dcs_seg_loss_final": [_P, _P, _I, _P],
     "dcs_scale_inplace": [_P, _L, _P, _P, _P],
@@ -64,7 +66,7 @@ SIGNATURES = {
     "dcs_dropout_bwd": [_P, _P, _P, _L, _F, _P],
     "dcs_adam_step": [_P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P],
     "dcs_axpy": [_P, _P, _L, _F, _P],
-    "dcs_add_rowvec_bcast": [_P, _P, _I, _L, _I, _F, _P],
+    "dcs_add_rowvec_bcast": [_P, _P, _I, _L, _I, _F, _I, _P],
     "dcs_relu_bwd_rows": [_P, _P, _P, _L, _P],
 }
 

@@ -207,8 +207,8 @@ class _SupConFn(torch.autograd.Function):
         ops.linear_wgrad(pooled, dh1, dw1)
         db1 = ops.colsum(dh1)[0, 0].contiguous()
         dpool = ops.linear(dh1, ops.transpose(w1c))
-        gfeat = torch.zeros((N, H, W, Cc), device=dF.device, dtype=dF.dtype)
-        ops.add_rowvec_bcast(gfeat, dpool, 1.0 / (H * W))
+        gfeat = torch.empty((N, H, W, Cc), device=dF.device, dtype=dF.dtype)
+        ops.add_rowvec_bcast(gfeat, dpool, 1.0 / (H * W), accumulate=False)
         return gfeat.permute(0, 3, 1, 2), None, dw1, db1, dw2, db2, None, None
 
 

@@ -394,8 +394,12 @@ class SwiftNetEngine:
                 g_cur = g_in
             elif kind == "stem":
                 _, idx, p, y, bn, pidx, bnm = item
-                gz = ops.maxpool_bwd(g_cur, pidx, y.shape[1], y.shape[2])
-                dy, _ = bn_bwd(bnm, gz, y, bn, relu=True)
+                acc = bnm.weight in grads
+                if not acc:
+                    grads[bnm.weight] = self._galloc(bnm.weight)
+                    grads[bnm.bias] = self._galloc(bnm.bias)
+                dy = ops.bn_pool_bwd(g_cur, pidx, y, bn, bnm.weight, dgamma=grads[bnm.weight], dbeta=grads[bnm.bias],
+                                     acc_param=acc, training=training)
                 if dwst is None:
                     dwst = torch.empty((64, 7, 8, 4), device=dy.device, dtype=dy.dtype)
                     ops.stem_wgrad(p, dy, dwst, False)

@@ -427,6 +427,23 @@ def maxpool_bwd(g, idx, H, W):
     return gz
 
 
+def bn_pool_bwd(g, idx, y, bn, gamma, dgamma=None, dbeta=None, acc_param=False, training=True):
+    """Backward of bn -> relu -> maxpool3x3/2 in one step: g [N,OH,OW,C] is the gradient of the POOLED map, idx the
+    saved argmax; returns dy [N,H,W,C] (gradient of the conv output y).  The dense gradient of the un-pooled map is
+    never written (it is re-gathered from g/idx in both BatchNorm passes)."""
+    _req(g), _req(y)
+    N, H, W, Cc = y.shape
+    grp = _groups((N * ((H + 1) // 2) * ((W + 1) // 2)) // 2)
+    part = torch.empty((grp, 2, Cc), device=y.device, dtype=_F32)
+    _call("dcs_bn_pool_bwd_partial", _p(g), _p(idx), _p(y), _p(bn), _p(part), N, H, W, Cc, grp, _stream())
+    sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
+    _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, _stream())
+    dy = torch.empty_like(y)
+    _call("dcs_bn_pool_bwd_apply", _p(g), _p(idx), _p(y), _p(bn), _p(gamma), _p(sums), _p(dy), _p(dgamma), _p(dbeta),
+          N, H, W, Cc, 1 if acc_param else 0, 1 if training else 0, _stream())
+    return dy
+
+
 def upsample_add(x, skips: Sequence[torch.Tensor], OH, OW):
     N, IH, IW, Cc = x.shape
     t = torch.empty((N, OH, OW, Cc), device=x.device, dtype=_F32)
@@ -454,7 +471,8 @@ def upsample_to_nchw(x, Cc, OH, OW):
 def upsample_to_nchw_bwd(g, IH, IW, cs, gscale=None):
     N, Cc, OH, OW = g.shape
     gx = torch.empty((N, IH, IW, cs), device=g.device, dtype=_F32)
-    _call("dcs_upsample_to_nchw_bwd", _p(_req(g)), _p(gscale), _p(gx), N, IH, IW, cs, Cc, OH, OW, _stream())
+    tmp = torch.empty((N, Cc, OH, IW), device=g.device, dtype=_F32) if Cc <= 32 else None
+    _call("dcs_upsample_to_nchw_bwd", _p(_req(g)), _p(gscale), _p(gx), _p(tmp), N, IH, IW, cs, Cc, OH, OW, _stream())
     return gx
 
 
@@ -602,9 +620,9 @@ def axpy(y, x, a):
     _call("dcs_axpy", _p(y), _p(x), x.numel(), float(a), _stream())
 
 
-def add_rowvec_bcast(g, v, scale):
+def add_rowvec_bcast(g, v, scale, accumulate=True):
     N, H, W, Cc = g.shape
-    _call("dcs_add_rowvec_bcast", _p(g), _p(_req(v)), N, H * W, Cc, float(scale), _stream())
+    _call("dcs_add_rowvec_bcast", _p(g), _p(_req(v)), N, H * W, Cc, float(scale), 1 if accumulate else 0, _stream())
 
 
 def relu_bwd(g, z):

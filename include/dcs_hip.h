@@ -131,6 +131,15 @@ int dcs_bn_relu_maxpool(const float* y, const float* bn, float* out, uint8_t* id
                         int C, void* stream);
 /* gz[n,iy,ix,c] = sum of g[outputs whose argmax is (iy,ix)]  (dense, y resolution). */
 int dcs_maxpool_bwd(const float* g, const uint8_t* idx, float* gz, int N, int H, int W, int C, void* stream);
+/* Backward of bn1 -> relu -> maxpool (resnet_pyramid.py:322-325) WITHOUT the dense pooled-gradient tensor: both passes
+ * gather the gradient of a 2x2 pixel quad from its four pooling windows (g, idx at [N,OH,OW,C]) on the fly.
+ * partial: [groups][2][C] (sum of masked gradient, sum of gradient * xhat) -> dcs_colsum_final -> sums [2][C];
+ * apply: dy [N,H,W,C] = BatchNorm input gradient, dgamma/dbeta written or accumulated.  y = saved conv output. */
+int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const float* y, const float* bn, float* partial,
+                            int N, int H, int W, int C, int groups, void* stream);
+int dcs_bn_pool_bwd_apply(const float* g, const uint8_t* idx, const float* y, const float* bn, const float* gamma,
+                          const float* sums, float* dy, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                          int acc_param, int training, void* stream);
 /* network/utils.py:92-102: t = bilinear(x -> [OH,OW], align_corners=False) + ((s0+s1)+s2). */
 int dcs_upsample_add(const float* x, const float* s0, const float* s1, const float* s2, float* t,
                      int N, int IH, int IW, int OH, int OW, int C, void* stream);
@@ -140,9 +149,11 @@ int dcs_upsample_bwd(const float* g, float* gx, int N, int IH, int IW, int OH, i
 /* network/utils.py:8 on the logits: x NHWC [N,IH,IW,cs] (first C channels) -> out NCHW [N,C,OH,OW]. */
 int dcs_upsample_to_nchw(const float* x, float* out, int N, int IH, int IW, int cs, int C, int OH, int OW,
                          void* stream);
-/* adjoint: g NCHW [N,C,OH,OW] * gscale -> gx NHWC [N,IH,IW,cs] (channels >= C zeroed). */
-int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, float* gx, int N, int IH, int IW, int cs,
-                             int C, int OH, int OW, void* stream);
+/* adjoint: g NCHW [N,C,OH,OW] * gscale -> gx NHWC [N,IH,IW,cs] (channels >= C zeroed).
+ * tmp: optional scratch of N*C*OH*IW floats; with it (and C <= 32) the adjoint runs as two separable passes
+ * (fold X, then fold Y + NHWC transpose) that read g exactly once. */
+int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, float* gx, float* tmp, int N, int IH, int IW,
+                             int cs, int C, int OH, int OW, void* stream);
 
 /* ---- segmentation losses (utils/loss.py:39-80; nn.CrossEntropyLoss) --------------------------
  * logits NCHW [N,C,H,W]; target int64 [N,H,W]; ldw [N,H,W]; cw [C].
@@ -208,8 +219,8 @@ int dcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
 
 /* elementwise helpers */
 int dcs_axpy(float* y, const float* x, int64_t n, float a, void* stream);           /* y += a*x */
-int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW, int C, float scale,
-                         void* stream);                                           /* g[n,p,c] += scale*v[n,c] */
+int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW, int C, float scale, int accumulate,
+                         void* stream);                /* g[n,p,c] (+)= scale*v[n,c]; accumulate=0 overwrites g */
 int dcs_relu_bwd_rows(const float* g, const float* z, float* out, int64_t n, void* stream); /* out = g*(z>0) */
 
 const char* dcs_version(void);

@@ -214,6 +214,12 @@ def maxpool_bwd(g, idx, H, W):
     return _nhwc(gz.reshape(N, C, H, W))
 
 
+def bn_pool_bwd(g, idx, y, bn, gamma, dgamma=None, dbeta=None, acc_param=False, training=True):
+    gz = maxpool_bwd(g, idx, y.shape[1], y.shape[2])
+    dy, _ = bn_bwd(gz, y, bn, gamma, relu=True, dgamma=dgamma, dbeta=dbeta, acc_param=acc_param, training=training)
+    return dy
+
+
 def upsample_add(x, skips, OH, OW):
     t = F.interpolate(_nchw(x), (OH, OW), mode="bilinear", align_corners=False)
     sk = 0
@@ -379,7 +385,9 @@ def axpy(y, x, a):
     y.add_(x, alpha=a)
 
 
-def add_rowvec_bcast(g, v, scale):
+def add_rowvec_bcast(g, v, scale, accumulate=True):
+    if not accumulate:
+        g.zero_()
     g.add_(v.view(v.shape[0], 1, 1, -1) * scale)
 
 

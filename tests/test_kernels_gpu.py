@@ -214,6 +214,19 @@ def test_bn_relu_maxpool_fwd_bwd(ops, N, H, W):
     close(out, oref, 1e-6, "pool fwd")
     g = rnd(*oref.shape, seed=29) * (oref > 0)      # positions with a zero maximum are ties; relu kills them anyway
     close(ops.maxpool_bwd(g.to(DEV), idx, H, W), E.maxpool_bwd(g, iref, H, W), 1e-6, "pool bwd")
+    # fused stem backward (pool adjoint gathered inside both BatchNorm passes) vs the two-step statement
+    bn[2], bn[3] = rnd(C, seed=30) * 0.1, 1.0 + 0.2 * rnd(C, seed=31).abs()
+    gamma = 1.0 + 0.1 * rnd(C, seed=32)
+    g2 = rnd(*oref.shape, seed=33)
+    for training, acc in ((True, False), (False, True)):
+        dg0, db0 = rnd(C, seed=34), rnd(C, seed=35)
+        dgd, dbd = dg0.to(DEV).clone(), db0.to(DEV).clone()
+        dy = ops.bn_pool_bwd(g2.to(DEV), idx, y.to(DEV), bn.to(DEV), gamma.to(DEV), dgamma=dgd, dbeta=dbd,
+                             acc_param=acc, training=training)
+        dgr, dbr = dg0.clone(), db0.clone()
+        ref = E.bn_pool_bwd(g2, iref, y, bn, gamma, dgamma=dgr, dbeta=dbr, acc_param=acc, training=training)
+        close(dy, ref, 2e-5, f"fused pool+bn bwd training={training}")
+        close(dgd, dgr, 2e-5, "fused pool+bn dgamma"); close(dbd, dbr, 2e-5, "fused pool+bn dbeta")
 
 
 @pytest.mark.parametrize("IH,IW,OH,OW", [(4, 8, 8, 16), (3, 5, 6, 10), (2, 3, 3, 5), (1, 2, 2, 3), (5, 7, 9, 12)])
@@ -239,6 +252,11 @@ def test_logits_upsample_and_adjoint(ops, IH, IW, OH, OW):
     close(ops.upsample_to_nchw(x.to(DEV), 19, OH, OW), E.upsample_to_nchw(x, 19, OH, OW), 2e-6, "logits up")
     g = rnd(2, 19, OH, OW, seed=38)
     close(ops.upsample_to_nchw_bwd(g.to(DEV), IH, IW, 20), E.upsample_to_nchw_bwd(g, IH, IW, 20), 1e-5, "logits up bwd")
+    gs = torch.tensor([0.37])
+    close(ops.upsample_to_nchw_bwd(g.to(DEV), IH, IW, 20, gscale=gs.to(DEV)), 0.37 * E.upsample_to_nchw_bwd(g, IH, IW, 20),
+          1e-5, "logits up bwd scaled")
+    g40 = rnd(1, 35, OH, OW, seed=39)          # > 32 classes: single-pass gather kernel
+    close(ops.upsample_to_nchw_bwd(g40.to(DEV), IH, IW, 36), E.upsample_to_nchw_bwd(g40, IH, IW, 36), 1e-5, "logits up bwd 35")
 
 
 @pytest.mark.parametrize("mode", ["full", "plain_focal", "no_class_weights", "no_EDT", "ce"])
@@ -339,6 +357,9 @@ def test_adam_and_small_helpers(ops):
     gd = gt.to(DEV).clone()
     ops.add_rowvec_bcast(gd, vv.to(DEV), 0.1)
     close(gd, gt + 0.1 * vv.view(2, 1, 1, 128), 1e-6, "bcast")
+    gw = torch.full((2, 3, 5, 128), float("nan"), device=DEV)
+    ops.add_rowvec_bcast(gw, vv.to(DEV), 0.1, accumulate=False)
+    close(gw, (0.1 * vv.view(2, 1, 1, 128)).expand(2, 3, 5, 128), 1e-6, "bcast write")
 
 
 def test_ops_refuse_cpu_tensors(ops):

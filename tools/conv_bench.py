@@ -21,6 +21,11 @@ SHAPES = [
     ("l4_512_32x64", 32, 32, 64, 512, 512, 3, 1),
     ("l2s2_64_128", 32, 256, 512, 64, 128, 3, 2),
     ("skip_64_128_1x1", 32, 256, 512, 64, 128, 1, 1),
+    ("sw_128_128_1x1", 32, 128, 256, 128, 128, 1, 1),
+    ("dl_256_1024_1x1", 8, 64, 128, 256, 1024, 1, 1),
+    ("dl_1024_256_1x1", 8, 64, 128, 1024, 256, 1, 1),
+    ("dl_64_256_1x1", 8, 256, 512, 64, 256, 1, 1),
+    ("dl_128_512_1x1", 8, 128, 256, 128, 512, 1, 1),
 ]
 
 
@@ -48,6 +53,8 @@ for name, N, H, W, Cin, Cout, k, s in SHAPES:
     out = []
     if which in ("fwd", "all"):
         ms = timeit(lambda: ops.conv_fwd(x, w, s, pad)); out.append(f"fwd {ms:7.3f} ms {flops/ms/1e9:6.1f} TF")
+    if which in ("fwdstats", "all"):
+        ms = timeit(lambda: ops.conv_fwd(x, w, s, pad, want_stats=True)); out.append(f"fwd+stats {ms:7.3f} ms {flops/ms/1e9:6.1f} TF")
     if which in ("dgrad", "all"):
         ms = timeit(lambda: ops.conv_dgrad(dy, wp, (H, W), s, pad)); out.append(f"dgrad {ms:7.3f} ms {flops/ms/1e9:6.1f} TF")
     if which in ("wgrad", "all"):
