@@ -20,7 +20,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -39,12 +38,12 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-template <int BN, bool STEM, int BKT>
-__global__ __launch_bounds__(256, BKT == 16 ? 3 : 2)
+template <int BN, bool STEM, int BKT, int BM = 128>
+__global__ __launch_bounds__(256, (BKT == 16 && BM * BN <= 128 * 128) ? 3 : 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                         const float* __restrict__ bias, float* __restrict__ dst,
                         const DcsConvGeom g, const int accumulate, const int ntiles, float* __restrict__ stats) {
-  constexpr int WN = BN >= 64 ? 2 : 1;
+  constexpr int WN = (BN >= 128 || (BN == 64 && BM == 128)) ? 2 : 1;
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (WM * 32);
   constexpr int TN = BN / (WN * 32);
@@ -54,7 +53,7 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   constexpr int NA = BM / RPP;           // A slots per thread
   constexpr int BROWS = BN / RPP;        // B slots per thread
   constexpr int NG = BKT / 8;            // MFMA k8 groups per chunk
-  static_assert(BROWS >= 1 && (NG == 4 || NG == 2), "unsupported tile");
+  static_assert(BROWS >= 1 && (NG == 4 || NG == 2) && (BM == 128 || BM == 256), "unsupported tile");
 
   // one array: As[2][BM*LDKT] followed by Bs[2][BN*LDKT]; the epilogue reuses it as per-wave staging tiles
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LDKT];
@@ -294,12 +293,20 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
       if (h == 0) { st[(wm * BN + cl) * 2] = s0; st[(wm * BN + cl) * 2 + 1] = s1; }
     }
     __syncthreads();
+    // one statistics row per 128 output pixels, whatever BM is (the host sizes the buffer for 128-pixel rows)
+    constexpr int HALVES = BM / 128, WPH = WM / HALVES;
+    static_assert(WPH >= 1, "a wave must not straddle two 128-pixel statistics rows");
     if (tid < BN && co0 + tid < g.Cout) {
-      float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) { s0 += st[(w * BN + tid) * 2]; s1 += st[(w * BN + tid) * 2 + 1]; }
-      stats[((long long)mtile * 2) * g.Cout + co0 + tid] = s0;
-      stats[((long long)mtile * 2 + 1) * g.Cout + co0 + tid] = s1;
+      for (int hh = 0; hh < HALVES; ++hh) {
+        const long long srow = (long long)mtile * HALVES + hh;
+        if ((unsigned long long)srow * 128ull >= (unsigned long long)M) break;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = hh * WPH; w < (hh + 1) * WPH; ++w) { s0 += st[(w * BN + tid) * 2]; s1 += st[(w * BN + tid) * 2 + 1]; }
+        stats[(srow * 2) * g.Cout + co0 + tid] = s0;
+        stats[(srow * 2 + 1) * g.Cout + co0 + tid] = s1;
+      }
     }
   }
 }
@@ -859,6 +866,11 @@ int check_geom(const DcsConvGeom* g) {
 // (32.5 KB LDS -> 4 blocks per CU; measured +4 % on 3x3 64->64 and +27 % on the bandwidth-bound 1x1 64->128);
 // 128-wide tiles measure the same either way and keep 32-channel chunks.  DCS_CONV_BK16 forces 16 everywhere.
 static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
+// 256-pixel tiles (DCS_CONV_BM256: 0 = never [default], 1 = 64-wide tiles only, 2 = also 128-wide tiles;
+// DCS_CONV_BM256_MIN = minimum grid size) measured the SAME as 128-pixel tiles on every C3 shape (113 / 135 TF):
+// the loss against peak is not per-tile overhead but MFMA-busy 78-89 % at a 2.0-2.35 GHz DVFS clock (PMC).
+static const int g_bm256 = getenv("DCS_CONV_BM256") ? atoi(getenv("DCS_CONV_BM256")) : 0;
+static const long long g_bm256_min_tiles = getenv("DCS_CONV_BM256_MIN") ? atoll(getenv("DCS_CONV_BM256_MIN")) : 2048;
 
 extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
                                const DcsConvGeom* geom, int accumulate, float* stats, void* stream) {
@@ -868,34 +880,39 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout);
   const long long M = (long long)geom->N * geom->TY * geom->TX;
   DCS_CHECK_ARG(M < 0x7FFFFF00ll);
-  const long long mtiles = (M + BM - 1) / BM;
   const int bn = geom->Cout > 64 ? 128 : (geom->Cout > 32 ? 64 : 32);
   const int ntiles = (geom->Cout + bn - 1) / bn;
-  const long long blocks = mtiles * ntiles;
-  DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
   DCS_CHECK_ARG(!(stats && accumulate));
   // few K chunks per tile (1x1 convolutions up to 512 channels): 16-channel chunks, 3 blocks per CU, so that the
   // prologue / epilogue of one tile overlaps the main loop of two others (measured +14..18 % on those shapes)
   const bool short_k = (long long)geom->ntaps * ((geom->K + 31) / 32) <= 16;
+  // 256-pixel tiles halve the per-tile prologue/epilogue share; used when the grid still fills the chip several times
+  const long long tiles256 = (M + 255) / 256 * ntiles;
+  const bool big = !geom->stem && g_bm256 != 0 && bn >= 64 && tiles256 >= g_bm256_min_tiles &&
+                   (bn == 64 || g_bm256 >= 2) && !short_k;
+  const int bm = big ? 256 : 128;
+  const long long mtiles = (M + bm - 1) / bm;
+  const long long blocks = mtiles * ntiles;
+  DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
   hipStream_t s = dcs_stream(stream);
-#define LAUNCH_GATHER(B)                                                                                              \
-  do {                                                                                                                \
-    if (geom->stem)                                                                                                   \
-      hipLaunchKernelGGL((conv_gather_kernel<B, true, 32>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias,  \
-                         dst, *geom, accumulate, ntiles, stats);                                                      \
-    else if (B == 64 || (B == 128 && (g_bk16 || short_k)))                                                                       \
-      hipLaunchKernelGGL((conv_gather_kernel<(B >= 64 ? B : 64), false, 16>), dim3((unsigned)blocks), dim3(256), 0, s, \
-                         src, wgt, bias, dst, *geom, accumulate, ntiles, stats);                                      \
-    else                                                                                                              \
-      hipLaunchKernelGGL((conv_gather_kernel<B, false, 32>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, \
-                         dst, *geom, accumulate, ntiles, stats);                                                      \
-  } while (0)
-  if (bn == 128)
-    LAUNCH_GATHER(128);
-  else if (bn == 64)
-    LAUNCH_GATHER(64);
-  else
-    LAUNCH_GATHER(32);
+#define LAUNCH_K(...)                                                                                                 \
+  hipLaunchKernelGGL((conv_gather_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, \
+                     *geom, accumulate, ntiles, stats)
+  if (geom->stem) {
+    if (bn == 128) LAUNCH_K(128, true, 32);
+    else if (bn == 64) LAUNCH_K(64, true, 32);
+    else LAUNCH_K(32, true, 32);
+  } else if (bn == 128) {
+    if (big) LAUNCH_K(128, false, 16, 256);
+    else if (g_bk16 || short_k) LAUNCH_K(128, false, 16);
+    else LAUNCH_K(128, false, 32);
+  } else if (bn == 64) {
+    if (big) LAUNCH_K(64, false, 16, 256);
+    else LAUNCH_K(64, false, 16);
+  } else {
+    LAUNCH_K(32, false, 32);
+  }
+#undef LAUNCH_K
   DCS_LAUNCH_RET();
 }
 

@@ -606,6 +606,19 @@ def confusion(logits, labels, num_classes, conf, lowres=None, want_pred=False):
     return pred
 
 
+def label_boundary_weights(labels, num_classes, ignore_id=255):
+    """labels int64 [B,H,W] on the device -> (weight fp32 [B,H,W], dist int32 [B,H,W] in 16.16 fixed point)."""
+    if labels.dtype != torch.int64 or not labels.is_contiguous() or not labels.is_cuda or labels.dim() != 3:
+        raise RuntimeError("label_boundary_weights: labels must be a contiguous int64 [B,H,W] device tensor "
+                           "(no CPU fallback)")
+    B, H, W = labels.shape
+    dist = torch.empty((B, H, W), device=labels.device, dtype=torch.int32)
+    weight = torch.empty((B, H, W), device=labels.device, dtype=_F32)
+    _call("dcs_label_boundary_weights", _p(labels), _p(dist), _p(weight), B, H, W, int(num_classes), int(ignore_id),
+          _stream())
+    return weight, dist
+
+
 def sum_scalar(x, scale=1.0):
     out = torch.empty((1,), device=x.device, dtype=_F32)
     _call("dcs_sum_scalar", _p(_req(x)), _p(out), x.numel(), float(scale), _stream())

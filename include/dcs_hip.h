@@ -217,6 +217,14 @@ int dcs_dropout_bwd(const float* g, const uint8_t* mask, float* out, int64_t n, 
 int dcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float wd, int step, void* stream);
 
+/* ---- boundary-aware label weights (dataloaders/custom_transforms_acdc.py:656-693, LabelBoundaryTransform) -----
+ * labels int64 [B,H,W]; dist int32 [B,H,W] scratch -> 16.16 fixed-point 3x3 chamfer (cv2.DIST_L2, maskSize 3)
+ * distance of every pixel to the nearest pixel with a different label (= the sum over classes of the per-class
+ * cv2.distanceTransform values the reference computes); weight [B,H,W] = exp(-d / (2 * std_image(d))), d = 0 for
+ * labels outside [0,num_classes), weight = 0 where label == ignore_id, std == 0 -> 1.  W <= 4096. */
+int dcs_label_boundary_weights(const int64_t* labels, int32_t* dist, float* weight, int B, int H, int W,
+                               int num_classes, int64_t ignore_id, void* stream);
+
 /* elementwise helpers */
 int dcs_axpy(float* y, const float* x, int64_t n, float a, void* stream);           /* y += a*x */
 int dcs_add_rowvec_bcast(float* g, const float* v, int N, int64_t HW, int C, float scale, int accumulate,

@@ -395,6 +395,18 @@ def relu_bwd(g, z):
     return g * (z > 0)
 
 
+def label_boundary_weights(labels, num_classes, ignore_id=255):
+    """Statement of the kernel's contract with the oracle's literal per-class transform."""
+    import numpy as np
+    from oracle import boundary_oracle as BO
+    ws, ds = [], []
+    for lab in labels.cpu().numpy():
+        ws.append(BO.label_boundary_transform(lab, num_classes, True, ignore_id))
+        per = BO.label_boundary_transform(lab, num_classes, False, ignore_id)
+        ds.append(np.rint(np.maximum(per, 0).sum(0).astype(np.float64) * 65536.0).astype(np.int32))
+    return torch.from_numpy(np.stack(ws)), torch.from_numpy(np.stack(ds))
+
+
 def install(monkeypatch):
     """Replace every public function of dcs_amd.ops by its emulation (test process only)."""
     import dcs_amd.ops as real
