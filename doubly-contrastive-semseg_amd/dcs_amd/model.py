@@ -490,6 +490,14 @@ class WeatherNet(nn.Module):
             self.feature_extractor = ResNetPyramid((3, 4, 6, 3))
         else:
             raise NotImplementedError
+        # resnet18_pyramid(pretrained=True) (resnet_pyramid.py:404): the reference downloads the ImageNet weights; here
+        # the same file is used when it is available LOCALLY (opts.pretrained_backbone_path, $DCS_IMAGENET_DIR or the
+        # torch hub cache), otherwise the backbone keeps its random initialisation (no network in this environment).
+        from .checkpoint import find_cached_imagenet, load_imagenet_backbone
+        path = getattr(opts, "pretrained_backbone_path", None) or find_cached_imagenet(backbone)
+        self.pretrained_from = path
+        if path:
+            load_imagenet_backbone(self.feature_extractor, path)
         self.segmentation = None
         if train_semantic:
             self.segmentation = _BNReluConv(self.feature_extractor.num_features, self.num_classes, k=1, bias=True)

@@ -38,9 +38,66 @@ class DcsAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (L2 weight decay folded into the gradient) on the fused HIP kernel."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, flat=None):
-        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        # same group keys as torch.optim.Adam so that state_dict() round-trips with the reference's optimizer
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False,
+                                      maximize=False, foreach=None, capturable=False, differentiable=False, fused=None,
+                                      decoupled_weight_decay=False))
         self.flat = flat                      # model.FlatBuffers or None
         self._flat_state = {}
+
+    # ---- torch.optim.Adam-compatible state (utils/init_trainer.py:258 restores it, trainer.py:417 saves it) ----
+    def state_dict(self):
+        """Flat moment buffers are exposed as per-parameter ``exp_avg`` / ``exp_avg_sq`` / ``step`` entries in the
+        reference's layout (stand-alone contiguous tensors)."""
+        synced = []
+        for gi, group in enumerate(self.param_groups):
+            st, fg = self._flat_state.get(gi), self._flat_group(group)
+            if st is None or fg is None:
+                continue
+            off = 0
+            for p in group["params"]:
+                self.state[p] = dict(step=torch.tensor(float(st["step"])),
+                                     exp_avg=torch.as_strided(st["m"], p.size(), p.stride(), off),
+                                     exp_avg_sq=torch.as_strided(st["v"], p.size(), p.stride(), off))
+                synced.append(p)
+                off += p.numel()
+        sd = super().state_dict()
+        for p in synced:                      # the flat buffers stay the only live copy of the moments
+            del self.state[p]
+        for entry in sd["state"].values():
+            for k, v in entry.items():
+                if torch.is_tensor(v):
+                    entry[k] = v.detach().clone(memory_format=torch.contiguous_format)
+            if not torch.is_tensor(entry.get("step")):
+                entry["step"] = torch.tensor(float(entry["step"]))
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._flat_state = {}
+        for gi, group in enumerate(self.param_groups):
+            fg = self._flat_group(group)
+            if fg is not None and all("exp_avg" in self.state.get(p, {}) for p in group["params"]):
+                m, v = torch.zeros_like(fg["flat_p"]), torch.zeros_like(fg["flat_p"])
+                off, steps = 0, set()
+                for p in group["params"]:
+                    s = self.state[p]
+                    torch.as_strided(m, p.size(), p.stride(), off).copy_(s["exp_avg"])
+                    torch.as_strided(v, p.size(), p.stride(), off).copy_(s["exp_avg_sq"])
+                    steps.add(int(s["step"]))
+                    off += p.numel()
+                    del self.state[p]
+                if len(steps) != 1:
+                    raise ValueError("parameters of one ADAM group carry different step counts: %s" % sorted(steps))
+                self._flat_state[gi] = dict(step=steps.pop(), m=m, v=v)
+                continue
+            for p in group["params"]:         # per-parameter path: moments in the parameter's own memory layout
+                s = self.state.get(p)
+                if s and "exp_avg" in s:
+                    for k in ("exp_avg", "exp_avg_sq"):
+                        if s[k].stride() != p.stride():
+                            s[k] = torch.empty_like(p).copy_(s[k])
+                    s["step"] = int(s["step"])
 
     def _flat_group(self, group):
         if self.flat is None:

@@ -195,3 +195,30 @@ def test_training_reduces_loss_at_bench_like_size():
     sd = ts.model.state_dict()
     assert int(sd["feature_extractor.layer1.0.bn1.num_batches_tracked"]) == 24
     assert int(sd["feature_extractor.bn1_0.num_batches_tracked"]) == 4
+
+
+def test_resume_from_checkpoint_continues_identically(tmp_path):
+    """trainer.py:407-423 + utils/init_trainer.py:246-279 on the device: a run restored from the checkpoint file
+    (model, flat ADAM moments, counters) takes the same next step as the run that wrote it.  The label weights of the
+    batch come from the device-side LabelBoundaryTransform."""
+    from dcs_amd.boundary import LabelBoundaryTransform
+    from dcs_amd.checkpoint import checkpoint_state, load_checkpoint, save_checkpoint
+    b, h, w = 2, 128, 256
+    img, labels, _, weather, cw = O.synthetic_batch(b, h, w, seed=9, cell=32)
+    ldw = LabelBoundaryTransform(19, reduce=True)({"label": labels.to(DEV)})["label_distance_weight"]
+    assert ldw.shape == labels.shape and float(ldw.max()) <= 1.0
+    sample = lambda: dict(left=img, label=labels.clone(), weather=weather, label_distance_weight=ldw)
+    a = build("pixelcontrast_focal", batch_size=b, cw=cw)
+    for it in range(2):
+        torch.manual_seed(it)
+        a.step(sample())
+    path = tmp_path / "latest_checkpoint.pth"
+    save_checkpoint(checkpoint_state(a.model, a.optimizer, epoch=0, num_iter=a.num_iter), path)
+    r = build("pixelcontrast_focal", batch_size=b, cw=cw)
+    meta = load_checkpoint(str(path), r.model, r.optimizer, continue_training=True, map_location=DEV)
+    assert meta["num_iter"] == 3
+    torch.manual_seed(7); oa = a.step(sample())
+    torch.manual_seed(7); orr = r.step(sample())
+    assert float(oa["total"]) == float(orr["total"])
+    for (k, va), vb in zip(a.model.state_dict().items(), r.model.state_dict().values()):
+        assert torch.equal(va, vb), k
