@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--criterion", default="supcon_pixelcontrast_focal")
     ap.add_argument("--model", default="resnet18", help="resnet18 (SwiftNet pyramid, C3/C4) or deeplabv3plus_resnet101 (C5)")
+    ap.add_argument("--lazy-ff0", action="store_true", help="DeepLab only: never materialise the upsampled 2048-channel "
+                    "fine_feat0 (dcs_amd.losses.LazyUpsampled); same losses and gradients")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--conv-report", default=None, help="write a per-shape conv timing table (json lines) to this file")
@@ -175,7 +177,8 @@ def main():
     left0, left1, labels, ldw, weather, cw = device_batch(O, b, args.height, args.width, 1000 * rank, two, dev)
     torch.manual_seed(1)
     deeplab = args.model.startswith("deeplab")
-    ts = TrainStep(make_opts(criterion=args.criterion, batch_size=b * world, model=args.model, deeplab=deeplab),
+    ts = TrainStep(make_opts(criterion=args.criterion, batch_size=b * world, model=args.model, deeplab=deeplab,
+                             lazy_fine_feat0=bool(args.lazy_ff0 and deeplab)),
                    class_weight=cw, device=dev)
     if world > 1:
         from dcs_amd.dist import DataParallelStep
@@ -223,7 +226,7 @@ def main():
         wg = ps.get("dcs_conv_wgrad", dict(tflops=0.0, avg_us=0.0, launches=0, ms=0.0))
         crops = 2 if two else 1
         line = {
-            "metric": "images/sec (2048x1024) SwiftNet-RN18 train step",
+            "metric": "images/sec (2048x1024) " + ("DeepLabV3+-RN101" if deeplab else "SwiftNet-RN18") + " train step",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -234,7 +237,8 @@ def main():
                        "model_images_per_sec": value * crops,
                        "conv_tflops_per_gpu_whole_step": value * crops * (3 * 2 * 631.6e9 if deeplab else 769.2e9) *
                                                          (args.height * args.width / (1024 * 2048)) / 1e12 / world,
-                       "final_loss": loss},
+                       "final_loss": loss, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
+                       **({"lazy_fine_feat0": bool(args.lazy_ff0)} if deeplab else {})},
             "roofline": {"bound": "mfma", "achieved": g["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": g["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(args, world),
                          "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c_pmc_traffic_c3.json)",

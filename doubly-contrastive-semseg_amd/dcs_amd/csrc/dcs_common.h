@@ -34,3 +34,18 @@ __device__ __forceinline__ float dcs_wave_max(float v) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+
+// Bilinear source taps of output index o for F.interpolate(mode="bilinear", align_corners=False) with an explicit output
+// size (torch's area_pixel_compute_source_index): scale = in / out.
+struct Lin { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lin lin_src(int o, float scale, int in) {
+  float s = scale * ((float)o + 0.5f) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  Lin l;
+  l.i0 = (int)s;
+  if (l.i0 > in - 1) l.i0 = in - 1;
+  l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
+  l.w1 = s - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}

@@ -193,6 +193,63 @@ __global__ void scatter_add_rows_kernel(const float* __restrict__ gX, const int3
   }
 }
 
+// Rows of a bilinearly upsampled map WITHOUT the map (network/utils.py:190 upsamples the 2048-channel DeepLab feature
+// to the logits' resolution only for utils/loss.py:391-415 to pick <= 608 pixels of it): row a = pixel rowidx[a] of the
+// virtual [N,OH,OW] grid, interpolated from feat [N,IH,IW,C] with the arithmetic of upsample_add_kernel.
+__global__ void gather_rows_bilinear_kernel(const float* __restrict__ feat, const int32_t* __restrict__ rowidx,
+                                            float* __restrict__ X, int A, int C, int IH, int IW, int OH, int OW) {
+  const int C4 = C >> 2;
+  const long long total = (long long)A * C4;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int a = (int)(i / C4), c = (int)(i % C4) * 4;
+    const int r = rowidx[a];
+    const int ox = r % OW, oy = (r / OW) % OH, n = r / (OW * OH);
+    const Lin ly = lin_src(oy, sy, IH), lx = lin_src(ox, sx, IW);
+    const float* b = feat + (long long)n * IH * IW * C + c;
+    const float4 v00 = *reinterpret_cast<const float4*>(b + ((long long)ly.i0 * IW + lx.i0) * C);
+    const float4 v01 = *reinterpret_cast<const float4*>(b + ((long long)ly.i0 * IW + lx.i1) * C);
+    const float4 v10 = *reinterpret_cast<const float4*>(b + ((long long)ly.i1 * IW + lx.i0) * C);
+    const float4 v11 = *reinterpret_cast<const float4*>(b + ((long long)ly.i1 * IW + lx.i1) * C);
+    float4 o;
+#define DCS_BL(f) fmaf(ly.w1, fmaf(lx.w1, v11.f, lx.w0 * v10.f), ly.w0 * fmaf(lx.w1, v01.f, lx.w0 * v00.f))
+    o.x = DCS_BL(x); o.y = DCS_BL(y); o.z = DCS_BL(z); o.w = DCS_BL(w);
+#undef DCS_BL
+    *reinterpret_cast<float4*>(X + (long long)a * C + c) = o;
+  }
+}
+
+// Adjoint: gfeat [N,IH,IW,C] += the four weighted taps of every row.  Different rows share taps, so one thread owns
+// (image n, channel group c) and walks the rows in order: deterministic, no atomics.
+__global__ void scatter_rows_bilinear_kernel(const float* __restrict__ gX, const int32_t* __restrict__ rowidx,
+                                             float* __restrict__ gfeat, int A, int C, int IH, int IW, int OH, int OW) {
+  const int C4 = C >> 2;
+  const int c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c4 >= C4) return;
+  const int n = blockIdx.y, c = c4 * 4;
+  const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  float* b = gfeat + (long long)n * IH * IW * C + c;
+  for (int a = 0; a < A; ++a) {
+    const int r = rowidx[a];
+    if (r / (OW * OH) != n) continue;
+    const int ox = r % OW, oy = (r / OW) % OH;
+    const Lin ly = lin_src(oy, sy, IH), lx = lin_src(ox, sx, IW);
+    const float4 g = *reinterpret_cast<const float4*>(gX + (long long)a * C + c);
+    const int ys[2] = {ly.i0, ly.i1}, xs[2] = {lx.i0, lx.i1};
+    const float wy[2] = {ly.w0, ly.w1}, wx[2] = {lx.w0, lx.w1};
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const float wgt = wy[j] * wx[k];
+        float4* d = reinterpret_cast<float4*>(b + ((long long)ys[j] * IW + xs[k]) * C);
+        float4 o = *d;
+        o.x = fmaf(wgt, g.x, o.x); o.y = fmaf(wgt, g.y, o.y); o.z = fmaf(wgt, g.z, o.z); o.w = fmaf(wgt, g.w, o.w);
+        *d = o;
+      }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // contrastive rows.  One 256-thread block per anchor row i.
 __device__ __forceinline__ float block_sum(float v, float* sm) {
@@ -404,6 +461,24 @@ extern "C" int dcs_scatter_add_rows(const float* gX, const int32_t* rowidx, floa
   DCS_CHECK_ARG(gX && rowidx && gfeat && A > 0 && C > 0 && (C & 3) == 0);
   hipLaunchKernelGGL(scatter_add_rows_kernel, dim3(grid_for((long long)A * C / 4)), dim3(256), 0, dcs_stream(stream), gX, rowidx,
                      gfeat, A, C);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_gather_rows_bilinear(const float* feat, const int32_t* rowidx, float* X, int A, int C, int N, int IH,
+                                        int IW, int OH, int OW, void* stream) {
+  DCS_CHECK_ARG(feat && rowidx && X && A > 0 && C > 0 && (C & 3) == 0 && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0);
+  DCS_CHECK_ARG((long long)N * OH * OW < (1ll << 31));
+  hipLaunchKernelGGL(gather_rows_bilinear_kernel, dim3(grid_for((long long)A * C / 4)), dim3(256), 0, dcs_stream(stream),
+                     feat, rowidx, X, A, C, IH, IW, OH, OW);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_scatter_rows_bilinear(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, int N, int IH,
+                                         int IW, int OH, int OW, void* stream) {
+  DCS_CHECK_ARG(gX && rowidx && gfeat && A > 0 && C > 0 && (C & 3) == 0 && N > 0 && N <= 65535);
+  DCS_CHECK_ARG(IH > 0 && IW > 0 && OH > 0 && OW > 0 && (long long)N * OH * OW < (1ll << 31));
+  hipLaunchKernelGGL(scatter_rows_bilinear_kernel, dim3((unsigned)((C / 4 + 63) / 64), (unsigned)N), dim3(64), 0,
+                     dcs_stream(stream), gX, rowidx, gfeat, A, C, IH, IW, OH, OW);
   DCS_LAUNCH_RET();
 }
 

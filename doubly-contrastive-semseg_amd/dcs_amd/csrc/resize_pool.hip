@@ -250,18 +250,7 @@ void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __rest
 }
 
 // ---- bilinear, align_corners=False, explicit output size (torch area_pixel_compute_source_index) -----
-struct Lin { int i0, i1; float w0, w1; };
-__device__ __forceinline__ Lin lin_src(int o, float scale, int in) {
-  float s = scale * ((float)o + 0.5f) - 0.5f;
-  if (s < 0.f) s = 0.f;
-  Lin l;
-  l.i0 = (int)s;
-  if (l.i0 > in - 1) l.i0 = in - 1;
-  l.i1 = l.i0 + (l.i0 < in - 1 ? 1 : 0);
-  l.w1 = s - (float)l.i0;
-  l.w0 = 1.f - l.w1;
-  return l;
-}
+// Lin / lin_src: dcs_common.h
 // total weight with which input index i enters output o
 __device__ __forceinline__ float lin_w(int o, float scale, int in, int i) {
   const Lin l = lin_src(o, scale, in);

@@ -99,7 +99,7 @@ class DeepLabHeadV3Plus(nn.Module):
 
 
 class _Saved:
-    __slots__ = ("tape", "training", "B", "Bm", "shapes")
+    __slots__ = ("tape", "training", "B", "Bm", "shapes", "lazy")
 
 
 class DeepLabEngine:
@@ -107,6 +107,7 @@ class DeepLabEngine:
         self.bb, self.head, self.num_classes = backbone, head, num_classes
         self.flat: Optional[FlatBuffers] = None
         self.dropout_noise = None          # test hook: callable(shape_nchw) -> 0/1 float tensor drawn on the host
+        self.lazy_ff0 = False              # set by DeepLabV3._get_engine
         self._seed = 0
 
     def _galloc(self, p):
@@ -210,7 +211,10 @@ class DeepLabEngine:
         zc = ops.bn_act(yc, bnc, relu=True)
         before = ops.conv_fwd(zc, c3.weight, 1, 0, bias=c3.bias, dst_cs=LOGIT_CS)
         seg = ops.upsample_to_nchw(before, self.num_classes, H, W)
-        ff0 = ops.upsample_add(f.contiguous(), [], h, w)                       # network/utils.py:190
+        if self.lazy_ff0:       # hand out the low-resolution map, rows are interpolated on demand
+            ff0 = out[:B] if B != Bm else out.view(out.shape)
+        else:
+            ff0 = ops.upsample_add(f.contiguous(), [], h, w)                   # network/utils.py:190
         for m in self._nbt:
             m.num_batches_tracked += 1
         self._nbt = []
@@ -221,6 +225,7 @@ class DeepLabEngine:
                          (lconv, lbn, yl, bnl, zl), (c0, cbn, yc, bnc, zc, up, c3), (hf, wf, h, w, H, W)))
             saved.tape, saved.training, saved.B, saved.Bm = tape, training, B, Bm
             saved.shapes = (out.shape, low.shape)
+            saved.lazy = self.lazy_ff0
         return seg, before, out, ff0, saved
 
     def _block_fwd(self, x, blk: Bottleneck, training, tape):
@@ -275,7 +280,10 @@ class DeepLabEngine:
         dev = f.device
         g_out = g_ff if g_ff is not None else torch.zeros(out_shape, device=dev, dtype=f.dtype)
         if g_ff0 is not None:
-            ops.upsample_bwd(g_ff0.contiguous(), hf, wf, out=g_out[:B], accumulate=True)
+            if saved.lazy:
+                ops.axpy(g_out[:B], g_ff0.contiguous(), 1.0)
+            else:
+                ops.upsample_bwd(g_ff0.contiguous(), hf, wf, out=g_out[:B], accumulate=True)
         g_low = None
         gb = None
         if g_seg is not None:
@@ -408,16 +416,21 @@ class _DeepLabFn(torch.autograd.Function):
 class DeepLabV3(nn.Module):
     """network/utils.py:159-194 (_SimpleSegmentationModel) with the HIP engine."""
 
-    def __init__(self, backbone: nn.ModuleDict, classifier: DeepLabHeadV3Plus, num_classes: int):
+    def __init__(self, backbone: nn.ModuleDict, classifier: DeepLabHeadV3Plus, num_classes: int,
+                 lazy_fine_feat0: bool = False):
         super().__init__()
         self.backbone = backbone
         self.classifier = classifier
         self.num_classes = num_classes
+        # False: the reference's 4-tuple (fine_feat0 = the upsampled [B,2048,h,w] tensor).  True: fine_feat0 is a
+        # losses.LazyUpsampled handle that PixelContrastLoss samples row by row (same values, no 4.3 GB tensor).
+        self.lazy_fine_feat0 = lazy_fine_feat0
         self._engine = None
 
     def _get_engine(self):
         if self._engine is None:
             object.__setattr__(self, "_engine", DeepLabEngine(self.backbone, self.classifier, self.num_classes))
+        self._engine.lazy_ff0 = bool(self.lazy_fine_feat0)
         return self._engine
 
     def flatten_parameters(self):
@@ -430,13 +443,18 @@ class DeepLabV3(nn.Module):
             ops.require_device(t, "left_img")
         seg, before, ff, ff0 = _DeepLabFn.apply(self._get_engine(), left_img, self.training, bool(return_supcon_feature),
                                                 torch.is_grad_enabled(), *list(self.parameters()))
-        return (seg, before[..., :self.num_classes].permute(0, 3, 1, 2), ff.permute(0, 3, 1, 2), ff0.permute(0, 3, 1, 2))
+        before_nchw = before[..., :self.num_classes].permute(0, 3, 1, 2)
+        if self.lazy_fine_feat0:
+            from .losses import LazyUpsampled
+            return seg, before_nchw, ff.permute(0, 3, 1, 2), LazyUpsampled(ff0.permute(0, 3, 1, 2), before_nchw.shape[-2:])
+        return seg, before_nchw, ff.permute(0, 3, 1, 2), ff0.permute(0, 3, 1, 2)
 
 
 def _segm_resnet(opts, layers, num_classes, output_stride):
     aspp_dilate = [12, 24, 36] if output_stride == 8 else [6, 12, 18]
     backbone = _resnet_backbone(layers, output_stride)
-    return DeepLabV3(backbone, DeepLabHeadV3Plus(2048, 256, num_classes, aspp_dilate), num_classes)
+    return DeepLabV3(backbone, DeepLabHeadV3Plus(2048, 256, num_classes, aspp_dilate), num_classes,
+                     lazy_fine_feat0=bool(getattr(opts, "lazy_fine_feat0", False)))
 
 
 def deeplabv3plus_resnet101(opts, num_classes=21, output_stride=8, pretrained_backbone=True):

@@ -32,8 +32,38 @@ def _scalar(g: torch.Tensor) -> torch.Tensor:
     return g.detach().reshape(1).contiguous()
 
 
-def global_avg_pool(x: torch.Tensor) -> torch.Tensor:
-    """nn.AdaptiveAvgPool2d((1,1)) + flatten on an [N,C,H,W]-shaped tensor -> [N,C]."""
+_POOL_W = {}
+
+
+def _upsample_colsum(n_in: int, n_out: int) -> torch.Tensor:
+    """sum over outputs o of the bilinear weight with which input i enters o (align_corners=False, fp32 like the kernels)."""
+    w = torch.zeros(n_in, dtype=torch.float32)
+    scale = torch.tensor(n_in, dtype=torch.float32) / torch.tensor(n_out, dtype=torch.float32)
+    s = (scale * (torch.arange(n_out, dtype=torch.float32) + 0.5) - 0.5).clamp_min(0.0)
+    i0 = s.floor().long().clamp_max(n_in - 1)
+    i1 = i0 + (i0 < n_in - 1).long()
+    w1 = s - i0.float()
+    w.index_add_(0, i0, 1.0 - w1)
+    w.index_add_(0, i1, w1)
+    return w
+
+
+def global_avg_pool(x) -> torch.Tensor:
+    """nn.AdaptiveAvgPool2d((1,1)) + flatten on an [N,C,H,W]-shaped tensor -> [N,C].  For a LazyUpsampled handle the
+    mean of the (virtual) upsampled map is a weighted sum of the low-resolution map: no upsampling."""
+    if isinstance(x, LazyUpsampled):
+        v = nhwc(x.lowres.detach())
+        N, hf, wf, Cc = v.shape
+        key = (hf, wf) + x.size + (str(v.device),)
+        if key not in _POOL_W:
+            wy, wx = _upsample_colsum(hf, x.size[0]), _upsample_colsum(wf, x.size[1])
+            w4 = torch.zeros((hf * wf, 4), dtype=torch.float32)
+            w4[:, 0] = (wy[:, None] * wx[None, :]).reshape(-1) / float(x.size[0] * x.size[1])
+            _POOL_W[key] = w4.to(v.device)
+        out = torch.empty((N, 4, Cc), device=v.device, dtype=v.dtype)
+        for n in range(N):
+            ops.linear_wgrad(v[n].reshape(hf * wf, Cc), _POOL_W[key].to(v.dtype), out[n])
+        return out[:, 0, :].contiguous()
     v = nhwc(x.detach())
     N, H, W, Cc = v.shape
     return ops.colsum(v.reshape(N * H * W, Cc), B=N, scale=1.0 / (H * W))[:, 0, :].contiguous()
@@ -282,6 +312,54 @@ class _PixelContrastFn(torch.autograd.Function):
         return gfeat.permute(0, 3, 1, 2), None, None, None, None
 
 
+class LazyUpsampled:
+    """``F.interpolate(lowres, size, mode="bilinear", align_corners=False)`` that is never materialised
+    (SURVEY.md 8(f) rank 4).  network/utils.py:190 upsamples DeepLab's 2048-channel feature to the logits' resolution
+    (4.3 GB per 4 images at 1024x2048, plus the same again for its gradient) only so that PixelContrastLoss can read
+    <= 608 pixels of it; bilinear interpolation is linear per pixel, so those rows are interpolated on demand and the
+    gradient goes straight back to the low-resolution map.  Quacks like the tensor for what the loss needs."""
+
+    def __init__(self, lowres: torch.Tensor, size):
+        self.lowres = lowres                      # logical NCHW [B,C,hf,wf] (autograd-connected)
+        self.size = (int(size[0]), int(size[1]))
+
+    @property
+    def shape(self):
+        return torch.Size((self.lowres.shape[0], self.lowres.shape[1]) + self.size)
+
+    @property
+    def device(self):
+        return self.lowres.device
+
+    @property
+    def dtype(self):
+        return self.lowres.dtype
+
+
+class _PixelContrastLazyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, lowres, rowidx, y, temperature, row_gather, size):
+        v = nhwc(lowres.detach())
+        X = ops.gather_rows_bilinear(v, rowidx, size[0], size[1])
+        if row_gather is None:
+            loss, dX = ops.contrast_fwd_bwd(X, y, 0, temperature)
+        else:
+            X_all, y_all, start = row_gather(X, y)
+            loss, dX_all = ops.contrast_fwd_bwd(X_all, y_all, 0, temperature)
+            dX = dX_all[start:start + X.shape[0]].contiguous()
+        ctx.saved = (dX, rowidx, tuple(v.shape), size)
+        return loss.reshape(()).clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        dX, rowidx, shape, size = ctx.saved
+        ctx.saved = None
+        ops.scale_inplace(dX, _scalar(g))
+        gfeat = torch.zeros(shape, device=dX.device, dtype=dX.dtype)
+        ops.scatter_rows_bilinear(dX, rowidx, gfeat, size[0], size[1])
+        return gfeat.permute(0, 3, 1, 2), None, None, None, None, None
+
+
 def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):
     """See _plan_anchor_requests.  torch.randperm on CPU is thread-count independent in its RESULT but, with
     several intra-op threads, takes 30-150 ms per call for 32K < n < 100K (measured, torch 2.10) instead of
@@ -412,4 +490,7 @@ class PixelContrastLoss(nn.Module, ABC):
         self.last_anchors = (img, cls, pix.view(n_view, T), n_view)
         if self.temperature != self.base_temperature:
             raise NotImplementedError("temperature != base_temperature")
+        if isinstance(feats, LazyUpsampled):
+            return _PixelContrastLazyFn.apply(feats.lowres, rowidx, y, float(self.temperature), self.row_gather,
+                                              feats.size)
         return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature), self.row_gather)

@@ -541,6 +541,23 @@ def scatter_add_rows(gX, rowidx, gfeat):
     _call("dcs_scatter_add_rows", _p(_req(gX)), _p(rowidx), _p(gfeat), rowidx.shape[0], gX.shape[1], _stream())
 
 
+def gather_rows_bilinear(feat, rowidx, OH, OW):
+    """feat NHWC [N,IH,IW,C]; rowidx int32 [A] into the virtual upsampled [N,OH,OW] grid -> X [A,C]."""
+    _req(feat)
+    N, IH, IW, Cc = feat.shape
+    A = rowidx.shape[0]
+    X = torch.empty((A, Cc), device=feat.device, dtype=_F32)
+    _call("dcs_gather_rows_bilinear", _p(feat), _p(rowidx), _p(X), A, Cc, N, IH, IW, OH, OW, _stream())
+    return X
+
+
+def scatter_rows_bilinear(gX, rowidx, gfeat, OH, OW):
+    """gfeat NHWC [N,IH,IW,C] += adjoint of gather_rows_bilinear."""
+    N, IH, IW, Cc = gfeat.shape
+    _call("dcs_scatter_rows_bilinear", _p(_req(gX)), _p(rowidx), _p(_req(gfeat)), rowidx.shape[0], Cc, N, IH, IW, OH, OW,
+          _stream())
+
+
 def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     """Contrastive loss on anchors X [A,C] (view-major) with float labels [A].
 

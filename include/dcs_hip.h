@@ -192,6 +192,13 @@ int dcs_scatter_add_rows(const float* gX, const int32_t* rowidx, float* gfeat, i
 int dcs_confusion(const float* logits, const int64_t* labels, uint8_t* pred_out, uint64_t* conf, int N, int C, int H,
                   int W, int lowres_h, int lowres_w, int cs, void* stream);
 
+/* Rows of a bilinear upsampling (align_corners=False) of feat [N,IH,IW,C] to [N,OH,OW] without materialising it
+ * (network/utils.py:190 + utils/loss.py:391-415): X[a] = upsampled pixel rowidx[a]; the adjoint adds the four weighted
+ * taps of every row into gfeat [N,IH,IW,C] in row order (deterministic). */
+int dcs_gather_rows_bilinear(const float* feat, const int32_t* rowidx, float* X, int A, int C, int N, int IH, int IW,
+                             int OH, int OW, void* stream);
+int dcs_scatter_rows_bilinear(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, int N, int IH, int IW,
+                              int OH, int OW, void* stream);
 /* ---- contrastive rows (utils/loss.py:175-204 and :361-386) -----------------------------------
  * S [A,ld] = C C^T (from dcs_conv_gather in 1x1 mode), scaled by inv_temp = 1/T on read.  For every row i < A:
  *   max-subtract, L2-normalise, masked exp/log reductions; loss_row[i]; G[i][j] = d(mean loss)/dS_ij

@@ -326,6 +326,20 @@ def scatter_add_rows(gX, rowidx, gfeat):
     gfeat.view(-1, C).index_add_(0, rowidx.long(), gX)
 
 
+def gather_rows_bilinear(feat, rowidx, OH, OW):
+    up = _nhwc(F.interpolate(_nchw(feat), (OH, OW), mode="bilinear", align_corners=False))
+    return up.reshape(-1, feat.shape[-1])[rowidx.long()].contiguous()
+
+
+@torch.enable_grad()
+def scatter_rows_bilinear(gX, rowidx, gfeat, OH, OW):
+    x = torch.zeros_like(gfeat).requires_grad_(True)
+    up = _nhwc(F.interpolate(_nchw(x), (OH, OW), mode="bilinear", align_corners=False))
+    rows = up.reshape(-1, gfeat.shape[-1])[rowidx.long()]
+    (g,) = torch.autograd.grad(rows, x, gX)
+    gfeat.add_(g)
+
+
 @torch.enable_grad()
 def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     x = X.detach().clone().requires_grad_(True)

@@ -21,9 +21,10 @@ def _gpu():
         pytest.skip("needs a GPU")
 
 
-def build(b, cw):
+def build(b, cw, lazy=False):
     from dcs_amd.trainer import TrainStep, make_opts
-    opts = make_opts(criterion="supcon_pixelcontrast_focal", batch_size=b, deeplab=True, model="deeplabv3plus_resnet101")
+    opts = make_opts(criterion="supcon_pixelcontrast_focal", batch_size=b, deeplab=True, model="deeplabv3plus_resnet101",
+                     lazy_fine_feat0=lazy)
     ts = TrainStep(opts, class_weight=cw, device=DEV)
     ts.model.load_state_dict(D.make_state(seed=7), strict=True)
     with torch.no_grad():
@@ -95,6 +96,35 @@ def test_deeplab_step_matches_oracle_and_trains():
         s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
         losses.append(float(ts.step((s0, dict(left=img[b:])))["total"].detach()))
     assert all(np.isfinite(losses)) and losses[-1] < losses[0], losses
+
+
+def test_lazy_fine_feat0_same_step_less_memory():
+    """Rows interpolated on demand (dcs_gather_rows_bilinear / dcs_scatter_rows_bilinear) against the materialised
+    [B,2048,h,w] tensor: identical sampled anchors and losses, gradients to fp32 summation order, lower peak memory."""
+    b, h, w = 2, 256, 512
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=83, two_crops=True, cell=32)
+    res = []
+    for lazy in (False, True):
+        torch.manual_seed(0)                       # same random weather-classifier head in both builds
+        ts = build(b, cw, lazy)
+        s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        torch.manual_seed(3)
+        torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
+        base = torch.cuda.memory_allocated()
+        out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - base          # what the step itself needed
+        keep = {k: out[k].detach().clone() for k in ("pixel", "total", "pred_weather")}
+        res.append((keep, {k: p.grad.clone() for k, p in ts.model.named_parameters()}, peak,
+                    ts.pixelcontrast_criterion.last_anchors[2].clone()))
+        del ts, out
+    (o0, g0, m0, a0), (o1, g1, m1, a1) = res
+    assert torch.equal(a0, a1)
+    assert float(o0["pixel"]) == float(o1["pixel"]) and abs(float(o0["total"]) - float(o1["total"])) < 1e-5 * abs(float(o0["total"]))
+    assert rel(o1["pred_weather"], o0["pred_weather"].detach().cpu().numpy()) < 1e-5
+    worst = max(float((g1[k] - g0[k]).norm()) / max(float(g0[k].norm()), 1e-12) for k in g0)
+    assert worst < 1e-4, worst
+    assert m1 < m0 - 2 * b * 2048 * (h // 4) * (w // 4) * 4 * 0.9, (m0, m1)    # feature + its gradient no longer allocated
 
 
 def test_deeplab_single_image_batch_raises_like_the_reference():

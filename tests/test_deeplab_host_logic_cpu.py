@@ -19,10 +19,10 @@ def emu(monkeypatch):
     emu_ops.install(monkeypatch)
 
 
-def build(dt=torch.float32, flat=True, b=2, cw=None):
+def build(dt=torch.float32, flat=True, b=2, cw=None, lazy=False):
     from dcs_amd.trainer import TrainStep, make_opts
     opts = make_opts(criterion="supcon_pixelcontrast_focal", batch_size=b, deeplab=True, model="deeplabv3plus_resnet101",
-                     dtype=dt, flat_params=flat)
+                     dtype=dt, flat_params=flat, lazy_fine_feat0=lazy)
     ts = TrainStep(opts, class_weight=cw, device="cpu")
     if dt == torch.float64:
         ts.model.double(); ts.supcon_criterion.double(); ts.weather_clf.double()
@@ -82,3 +82,31 @@ def test_deeplab_engine_matches_oracle_fp64_odd_size(emu):
             assert float((sd[k] - v).abs().max()) < 1e-9, k
         if "num_batches" in k:
             assert int(sd[k]) == int(v), k
+
+
+def test_lazy_fine_feat0_is_the_same_step(emu):
+    """with ``lazy_fine_feat0`` the [B,2048,h,w] upsampled feature is never built; anchors are
+    interpolated row by row.  Same losses, weather logits and gradients as the materialised path (float64: to rounding)."""
+    from dcs_amd.losses import LazyUpsampled
+    dt = torch.float64
+    b, h, w = 2, 72, 104
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=71, two_crops=True, cell=16)
+    outs, grads = [], []
+    for lazy in (False, True):
+        torch.manual_seed(0)                       # same random weather-classifier head in both builds
+        ts, _, _ = build(dt, flat=False, b=b, cw=cw.to(dt), lazy=lazy)
+        s0 = dict(left=img[:b].to(dt), label=labels.clone(), weather=weather, label_distance_weight=ldw.to(dt))
+        torch.manual_seed(5)
+        out = ts.step((s0, dict(left=img[b:].to(dt))), do_optimizer_step=False)
+        outs.append(out)
+        grads.append({k: p.grad.clone() for k, p in ts.model.named_parameters()})
+        if lazy:
+            ff0 = ts.model(img[:b].to(dt))[3]
+            assert isinstance(ff0, LazyUpsampled) and tuple(ff0.shape) == (b, 2048, h // 4, w // 4)
+    for k in ("total", "pixel", "supcon", "seg"):
+        assert abs(float(outs[0][k]) - float(outs[1][k])) < 1e-10 * max(1.0, abs(float(outs[0][k]))), k
+    # pooled weights of the lazy path are built in fp32 like the kernels' interpolation weights
+    assert float((outs[0]["pred_weather"] - outs[1]["pred_weather"]).abs().max()) < 1e-6
+    for k, g0 in grads[0].items():
+        err = float((grads[1][k] - g0).abs().max()) / max(float(g0.abs().max()), 1e-12)
+        assert err < 1e-9, (k, err)
