@@ -38,6 +38,99 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// Epilogue shared by the convolution kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Each wave transposes its accumulators 32 rows at a time through a private
+// LDS tile and writes 16 B per lane (a quarter wave covers one contiguous run of the pixel's channels) instead of
+// 4-byte column-strided stores.  With `stats`, the per-channel sum and sum of squares of this block's outputs (the
+// BatchNorm batch statistics of the layer that follows) are reduced in fixed order and written to
+// stats[128-pixel row][2][Cout], so the activation is not read again by a separate reduction pass.
+// smem: the block's LDS (free after the main loop's final barrier); rowoff[BM]: element offset of every tile row in
+// dst, or -1; wave (wm, wn) owns rows wm*TM*32.. and columns wn*TN*32.. of the tile.
+template <int BM, int BN, int TM, int TN, int WM, int SMEM_FLOATS>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem, const long long* rowoff,
+                                              const float* __restrict__ bias, float* __restrict__ dst,
+                                              const int dst_cstride, const int Cout, const int co0, const int accumulate,
+                                              float* __restrict__ stats, const long long mtile,
+                                              const unsigned long long M, const int wm, const int wn) {
+  constexpr int EPC = TN * 32;            // columns of a wave's sub-tile
+  constexpr int EPL = EPC + 4;            // staging row stride (16-B aligned rows, conflict-free column writes)
+  constexpr int EPV = EPC / 4;            // float4 per staged row
+  constexpr int EPR = 64 / EPV;           // rows per read-back pass
+  static_assert(4 * 32 * EPL + WM * BN * 2 <= SMEM_FLOATS, "staging does not fit");
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  float* stg = smem + wid * (32 * EPL);
+  float* st = smem + 4 * 32 * EPL;        // [WM][BN][2] statistics scratch
+  const bool vec_ok = (dst_cstride & 3) == 0 && (reinterpret_cast<unsigned long long>(dst) & 15ull) == 0;
+  float ssum[TN], ssq[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) { ssum[b] = 0.f; ssq[b] = 0.f; }
+#pragma unroll
+  for (int a = 0; a < TM; ++a) {
+    const int row0 = wm * TM * 32 + a * 32;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int col = co0 + wn * EPC + b * 32 + l31;
+      const float bvv = (bias && col < Cout) ? bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[a][b][r] + bvv;
+        stg[rl * EPL + b * 32 + l31] = v;
+        if (stats && rowoff[row0 + rl] >= 0) { ssum[b] += v; ssq[b] = fmaf(v, v, ssq[b]); }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int c4 = lane % EPV, rr = lane / EPV;
+    const int colv = co0 + wn * EPC + c4 * 4;
+#pragma unroll
+    for (int p = 0; p < 32 / EPR; ++p) {
+      const int rl = p * EPR + rr;
+      const long long ro = rowoff[row0 + rl];
+      if (ro < 0 || colv >= Cout) continue;
+      float4 v = ld4(&stg[rl * EPL + c4 * 4]);
+      float* q = dst + ro + colv;
+      if (vec_ok && colv + 3 < Cout) {
+        if (accumulate) { const float4 o = ld4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        *reinterpret_cast<float4*>(q) = v;
+      } else {
+        const float vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (colv + e < Cout) q[e] = accumulate ? q[e] + vv[e] : vv[e];
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (stats) {
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int cl = wn * EPC + b * 32 + l31;
+      float s0 = ssum[b], s1 = ssq[b];
+      s0 += __shfl_xor(s0, 32, 64);
+      s1 += __shfl_xor(s1, 32, 64);
+      if (h == 0) { st[(wm * BN + cl) * 2] = s0; st[(wm * BN + cl) * 2 + 1] = s1; }
+    }
+    __syncthreads();
+    // one statistics row per 128 output pixels, whatever BM is (the host sizes the buffer for 128-pixel rows)
+    constexpr int HALVES = BM / 128, WPH = WM / HALVES;
+    static_assert(WPH >= 1, "a wave must not straddle two 128-pixel statistics rows");
+    if (tid < BN && co0 + tid < Cout) {
+#pragma unroll
+      for (int hh = 0; hh < HALVES; ++hh) {
+        const long long srow = mtile * HALVES + hh;
+        if ((unsigned long long)srow * 128ull >= M) break;
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int w = hh * WPH; w < (hh + 1) * WPH; ++w) { s0 += st[(w * BN + tid) * 2]; s1 += st[(w * BN + tid) * 2 + 1]; }
+        stats[(srow * 2) * Cout + co0 + tid] = s0;
+        stats[(srow * 2 + 1) * Cout + co0 + tid] = s1;
+      }
+    }
+  }
+}
+
 template <int BN, bool STEM, int BKT, int BM = 128>
 __global__ __launch_bounds__(256, (BKT == 16 && BM * BN <= 128 * 128) ? 3 : 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
@@ -227,88 +320,8 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     __syncthreads();
   }
 
-  // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
-  // Each wave transposes its accumulators 32 rows at a time through a private LDS tile and writes 16 B per lane
-  // (a quarter wave covers one contiguous run of the pixel's channels) instead of 4-byte column-strided stores.
-  // With `stats`, the per-channel sum and sum of squares of this block's outputs (the BatchNorm batch statistics
-  // of the layer that follows) are reduced here in fixed order and written to stats[mtile][2][Cout], so the
-  // activation is not read again by a separate reduction pass.
-  constexpr int EPC = TN * 32;            // columns of a wave's sub-tile
-  constexpr int EPL = EPC + 4;            // staging row stride (16-B aligned rows, conflict-free column writes)
-  constexpr int EPV = EPC / 4;            // float4 per staged row
-  constexpr int EPR = 64 / EPV;           // rows per read-back pass
-  static_assert(4 * 32 * EPL + WM * BN * 2 <= 2 * (BM + BN) * LDKT, "staging does not fit");
-  float* stg = smem + wid * (32 * EPL);
-  float* st = smem + 4 * 32 * EPL;        // [WM][BN][2] statistics scratch
-  const bool vec_ok = (g.dst_cstride & 3) == 0 && (reinterpret_cast<unsigned long long>(dst) & 15ull) == 0;
-  float ssum[TN], ssq[TN];
-#pragma unroll
-  for (int b = 0; b < TN; ++b) { ssum[b] = 0.f; ssq[b] = 0.f; }
-#pragma unroll
-  for (int a = 0; a < TM; ++a) {
-    const int row0 = wm * TM * 32 + a * 32;
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int col = co0 + wn * EPC + b * 32 + l31;
-      const float bvv = (bias && col < g.Cout) ? bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = acc[a][b][r] + bvv;
-        stg[rl * EPL + b * 32 + l31] = v;
-        if (stats && rowoff[row0 + rl] >= 0) { ssum[b] += v; ssq[b] = fmaf(v, v, ssq[b]); }
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const int c4 = lane % EPV, rr = lane / EPV;
-    const int colv = co0 + wn * EPC + c4 * 4;
-#pragma unroll
-    for (int p = 0; p < 32 / EPR; ++p) {
-      const int rl = p * EPR + rr;
-      const long long ro = rowoff[row0 + rl];
-      if (ro < 0 || colv >= g.Cout) continue;
-      float4 v = ld4(&stg[rl * EPL + c4 * 4]);
-      float* q = dst + ro + colv;
-      if (vec_ok && colv + 3 < g.Cout) {
-        if (accumulate) { const float4 o = ld4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *reinterpret_cast<float4*>(q) = v;
-      } else {
-        const float vv[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (colv + e < g.Cout) q[e] = accumulate ? q[e] + vv[e] : vv[e];
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (stats) {
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int cl = wn * EPC + b * 32 + l31;
-      float s0 = ssum[b], s1 = ssq[b];
-      s0 += __shfl_xor(s0, 32, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      if (h == 0) { st[(wm * BN + cl) * 2] = s0; st[(wm * BN + cl) * 2 + 1] = s1; }
-    }
-    __syncthreads();
-    // one statistics row per 128 output pixels, whatever BM is (the host sizes the buffer for 128-pixel rows)
-    constexpr int HALVES = BM / 128, WPH = WM / HALVES;
-    static_assert(WPH >= 1, "a wave must not straddle two 128-pixel statistics rows");
-    if (tid < BN && co0 + tid < g.Cout) {
-#pragma unroll
-      for (int hh = 0; hh < HALVES; ++hh) {
-        const long long srow = (long long)mtile * HALVES + hh;
-        if ((unsigned long long)srow * 128ull >= (unsigned long long)M) break;
-        float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-        for (int w = hh * WPH; w < (hh + 1) * WPH; ++w) { s0 += st[(w * BN + tid) * 2]; s1 += st[(w * BN + tid) * 2 + 1]; }
-        stats[(srow * 2) * g.Cout + co0 + tid] = s0;
-        stats[(srow * 2 + 1) * g.Cout + co0 + tid] = s1;
-      }
-    }
-  }
+  conv_epilogue<BM, BN, TM, TN, WM, 2 * (BM + BN) * LDKT>(acc, smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0,
+                                                          accumulate, stats, mtile, M, wm, wn);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -869,6 +882,8 @@ static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
 // 256-pixel tiles (DCS_CONV_BM256: 0 = never [default], 1 = 64-wide tiles only, 2 = also 128-wide tiles;
 // DCS_CONV_BM256_MIN = minimum grid size) measured the SAME as 128-pixel tiles on every C3 shape (113 / 135 TF):
 // the loss against peak is not per-tile overhead but MFMA-busy 78-89 % at a 2.0-2.35 GHz DVFS clock (PMC).
+// Also measured and dropped: a 3x3 kernel with the 6x34-pixel input halo resident in LDS (5.6x fewer A loads, 144 MFMAs
+// per wave between barriers): 3-5 % SLOWER than this per-tap kernel on every C3 shape.
 static const int g_bm256 = getenv("DCS_CONV_BM256") ? atoi(getenv("DCS_CONV_BM256")) : 0;
 static const long long g_bm256_min_tiles = getenv("DCS_CONV_BM256_MIN") ? atoll(getenv("DCS_CONV_BM256_MIN")) : 2048;
 
