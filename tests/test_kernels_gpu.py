@@ -56,10 +56,10 @@ CONV_CASES = [
     (3, 3, 96, 64, 128, 3, 1),
     (1, 2, 32, 256, 256, 3, 1),
     (3, 300, 320, 64, 64, 1, 1),     # 2250 row tiles: two-level reduction of the fused BN statistics
-    (2, 8, 64, 64, 64, 3, 1),        # H % 4 == 0 and W % 32 == 0: halo-resident 3x3 kernel (64-wide tiles)
-    (1, 12, 32, 32, 40, 3, 1),       # ... ragged output channels
-    (2, 4, 96, 16, 64, 3, 1),        # ... a single K slice
-    (1, 8, 32, 128, 128, 3, 1),      # ... 128-wide tiles (DCS_CONV_HALO=2)
+    (2, 8, 64, 64, 64, 3, 1),
+    (1, 12, 32, 32, 40, 3, 1),       # ragged output channels
+    (2, 4, 96, 16, 64, 3, 1),        # a single 16-channel K chunk per tap
+    (1, 8, 32, 128, 128, 3, 1),
 ]
 
 
