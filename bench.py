@@ -149,6 +149,49 @@ def pmc_traffic(args, world):
         return json.load(f)["conv_gather"]["hbm_bytes_per_launch"]
 
 
+def similarity_bench(ops, dev, ts, reps=20):
+    """BASELINE.json's second metric: TFLOP/s of the embedding-similarity kernels of the pixel-contrastive loss
+    (S = X X^T forward, dX = (G + G^T) X backward; utils/loss.py:339-389), outside the timed region, HIP events.
+    A = anchors this rank sampled in the last step (<= 608 rows of 128) and A_global = the 8-rank gathered set of C4."""
+    la = ts.pixelcontrast_criterion.last_anchors
+    a_rank = int(la[2].numel()) if la is not None else 608
+    out = {"unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS, "dim": 128}
+    for tag, A in (("rank", a_rank), ("global", 8 * a_rank)):
+        gen = torch.Generator(device="cpu").manual_seed(A)
+        X = torch.nn.functional.normalize(torch.randn(A, 128, generator=gen), dim=1).to(dev)
+        y = torch.randint(0, 19, (A,), generator=gen).float().to(dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        for _ in range(3):
+            ops.contrast_fwd_bwd(X, y, 0, 0.07)
+        ev[0].record()
+        for _ in range(reps):
+            ops.contrast_fwd_bwd(X, y, 0, 0.07)
+        ev[1].record()
+        torch.cuda.synchronize()
+        us = ev[0].elapsed_time(ev[1]) / reps * 1e3
+        flops = 6.0 * A * A * 128                       # fwd 2 A^2 d + bwd 4 A^2 d (SURVEY.md 8(d))
+        # the two GEMMs alone (the rest of the loss is row reductions)
+        ld = -(-A // 32) * 32
+        Gs = torch.randn(A, ld, generator=gen).to(dev)
+        dXp = torch.empty((ld, 128), device=dev)
+        Xt = ops.transpose(X if ld == A else torch.cat([X, X.new_zeros(ld - A, 128)]))
+        bwd = (lambda: ops.linear_wgrad(X, Gs, dXp)) if A > 1024 else (lambda: ops.linear(Gs, Xt))   # as contrast_fwd_bwd
+        tg = []
+        for fn in (lambda: ops.linear(X, X), bwd):
+            fn(); ev[0].record()
+            for _ in range(reps):
+                fn()
+            ev[1].record(); torch.cuda.synchronize()
+            tg.append(ev[0].elapsed_time(ev[1]) / reps * 1e3)
+        out[tag] = {"A": A, "loss_fwd_bwd_us": us, "loss_tflops": flops / us / 1e6,
+                    "gemm_fwd_us": tg[0], "gemm_fwd_tflops": 2.0 * A * A * 128 / tg[0] / 1e6,
+                    "gemm_bwd_us": tg[1], "gemm_bwd_tflops": 2.0 * A * ld * 128 / tg[1] / 1e6}
+    gl = out["global"]
+    out["similarity_kernel_frac_global"] = gl["gemm_fwd_tflops"] / PEAK_FP32_MFMA_TFLOPS    # S = X X^T at the C4 size
+    out["note"] = "rank-size kernels (A <= 608) are launch-latency bound: 95 MFLOP = 0.6 us at peak"
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,6 +294,7 @@ def main():
                                           "ms_per_step": wg["ms"] / max(args.steps, 1),
                                           "launches_per_step": wg["launches"] // max(args.steps, 1)}},
         }
+        line["similarity"] = similarity_bench(ops, dev, ts)
         if args.conv_report:
             with open(args.conv_report, "w") as f:
                 for r in prof.per_shape():

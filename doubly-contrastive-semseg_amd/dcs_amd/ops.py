@@ -310,11 +310,13 @@ def transpose(x):
 
 
 def linear_wgrad(x, dy, dw, accumulate=False):
-    """dw [Cout,K] (+)= dy^T x."""
+    """dw [Cout,K] (+)= dy^T x (reduction over the rows, split over row ranges like the conv weight gradient)."""
     rows, K = x.shape
     Cout = dy.shape[1]
     g = geom_fwd(rows, 1, 1, K, Cout, 1, 1, 1, 0)
-    ns = 1
+    bt = 128 if (Cout > 64 and K > 64) else 64
+    tiles = (-(-Cout // bt)) * (-(-K // bt))
+    ns = max(1, min(-(-512 // tiles), rows // 512))      # about two blocks per CU, >= 16 row chunks per block
     slab = torch.empty((ns, Cout * K), device=x.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(_req(x)), _p(_req(dy)), _p(slab), C.byref(g), Cout, 0, ns, _stream())
     _call("dcs_reduce_slab", _p(slab), _p(dw), Cout * K, ns, 1 if accumulate else 0, 0, 0, _stream())
@@ -577,7 +579,14 @@ def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     _call("dcs_sum_scalar", _p(loss_row), _p(loss), A, 1.0 / A, _stream())
     Gs = torch.empty((A, ld), device=X.device, dtype=_F32)
     _call("dcs_symmetrize", _p(G), _p(Gs), A, ld, _stream())
-    # dX = (G + G^T) X : GEMM with K = ld (zero padded), weights = X^T [C, ld]
+    if A > 1024:
+        # dX = (G + G^T) X.  Gs is symmetric, so dX[i] = sum_j Gs[j][i] X[j]: a "weight gradient" GEMM (reduction over
+        # the rows j, split over row ranges), which fills the chip where the row-tiled form has only A/128 blocks
+        # (the gathered global batch of the data-parallel step: A up to 4864).
+        dXp = torch.empty((ld, Cc), device=X.device, dtype=_F32)
+        linear_wgrad(X, Gs, dXp)
+        return loss, dXp[:A]
+    # per-rank size (A <= 608): launch-latency bound either way; row-tiled GEMM with K = ld (zero padded), weights X^T
     Xp = X
     if ld != A:
         Xp = torch.zeros((ld, Cc), device=X.device, dtype=_F32)

@@ -327,7 +327,8 @@ def test_gather_scatter_rows(ops):
     close(gfd, ref, 1e-7, "scatter")
 
 
-@pytest.mark.parametrize("A,mode", [(8, 1), (64, 1), (76, 0), (304, 0), (608, 0), (33, 0)])
+@pytest.mark.parametrize("A,mode", [(8, 1), (64, 1), (76, 0), (304, 0), (608, 0), (33, 0),
+                                    (1216, 0), (2437, 0)])      # > 1024 anchors (gathered global batch): split-row backward GEMM
 def test_contrast_fwd_bwd(ops, A, mode):
     g = np.random.default_rng(47 + A)
     X = rnd(A, 128, seed=48 + A) * 0.7
