@@ -23,8 +23,8 @@ namespace {
 constexpr int HV = 62587;            // cvRound(0.955f  * 65536)
 constexpr int DG = 89738;            // cvRound(1.3693f * 65536)
 constexpr int FAR = 0x7FFFFFFF >> 2; // OpenCV DIST_MAX
-constexpr int EPT = 4;               // columns per thread -> W <= 4096
-constexpr int NT = 1024;
+constexpr int NT = 512;
+constexpr int MAX_EPT = 8;           // columns per thread -> W <= 4096
 
 __global__ __launch_bounds__(256)
 void boundary_seed_kernel(const long long* __restrict__ lab, int* __restrict__ dist, int B, int H, int W) {
@@ -55,37 +55,41 @@ void boundary_seed_kernel(const long long* __restrict__ lab, int* __restrict__ d
 
 __device__ __forceinline__ int sat_add(int v, int inc) { const int r = v + inc; return r < FAR ? r : FAR; }
 
-// inclusive prefix minimum over the block's NT * ept values (thread-contiguous), 64-bit keys
-__device__ __forceinline__ void block_prefix_min(long long v[EPT], int ept, long long* wave_tot) {
+// inclusive prefix minimum over the block's NT * ept values (thread-contiguous).  Keys t - a*x fit 32 bits:
+// t <= FAR = 2^29, a*x < 62587 * 4096 = 2^28.
+template <int EPT>
+__device__ __forceinline__ void block_prefix_min(int (&v)[EPT], int* wave_tot) {
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int e = 1; e < ept; ++e) v[e] = v[e] < v[e - 1] ? v[e] : v[e - 1];
-  long long run = v[ept - 1];
+#pragma unroll
+  for (int e = 1; e < EPT; ++e) v[e] = v[e] < v[e - 1] ? v[e] : v[e - 1];
+  int run = v[EPT - 1];
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
-    const long long other = __shfl_up(run, o, 64);
+    const int other = __shfl_up(run, o, 64);
     if (lane >= o && other < run) run = other;
   }
   if (lane == 63) wave_tot[wid] = run;
   __syncthreads();
-  long long pre = 0x7FFFFFFFFFFFFFFFll;
+  int pre = 0x7FFFFFFF;
   for (int w = 0; w < wid; ++w) pre = wave_tot[w] < pre ? wave_tot[w] : pre;
-  const long long left = __shfl_up(run, 1, 64);
+  const int left = __shfl_up(run, 1, 64);
   if (lane > 0 && left < pre) pre = left;
-  for (int e = 0; e < ept; ++e) v[e] = v[e] < pre ? v[e] : pre;
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) v[e] = v[e] < pre ? v[e] : pre;
 }
 
+// EPT (columns per thread) is a compile-time constant so that the per-row values live in registers and the loads of
+// row r+1 stay in flight across the scan of row r (with a run-time trip count hipcc waits for every load at once).
+template <int EPT>
 __global__ __launch_bounds__(NT)
-void boundary_sweep_kernel(const long long* __restrict__ lab, int* __restrict__ dist, float* __restrict__ weight, int H,
-                           int W, int num_classes, long long ignore_id) {
+void boundary_sweep_kernel(const long long* __restrict__ lab, int* __restrict__ dist, float* __restrict__ img_std, int H,
+                           int W, int num_classes) {
   extern __shared__ int rowbuf[];            // [2][W + 2], entries 0 and W+1 stay FAR
-  __shared__ long long wave_tot[2][NT / 64];
+  __shared__ int wave_tot[2][NT / 64];
   __shared__ double red[2][NT / 64];
-  __shared__ float s_std;
   const int tid = threadIdx.x;
-  const int ept = (W + NT - 1) / NT;
   const long long* li = lab + (long long)blockIdx.x * H * W;
   int* di = dist + (long long)blockIdx.x * H * W;
-  float* wi = weight + (long long)blockIdx.x * H * W;
   const int RW = W + 2;
   for (int i = tid; i < 2 * RW; i += NT) rowbuf[i] = FAR;
   __syncthreads();
@@ -97,34 +101,55 @@ void boundary_sweep_kernel(const long long* __restrict__ lab, int* __restrict__ 
       for (int i = tid; i < 2 * RW; i += NT) rowbuf[i] = FAR;
       __syncthreads();
     }
+    // the row's own values (seeds in pass 0, forward distances in pass 1) and, in pass 1, its labels are fetched one
+    // row ahead: the row-to-row dependency goes through LDS only, so no global-memory latency sits on the chain
+    int tv[EPT];
+    long long lv[EPT];
+    auto fetch = [&](int r) {
+      const int y = pass ? H - 1 - r : r;
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int xs = tid * EPT + e;
+        if (r < H && xs < W) {
+          const int x = pass ? W - 1 - xs : xs;
+          tv[e] = di[(long long)y * W + x];
+          if (pass == 1) lv[e] = li[(long long)y * W + x];
+        }
+      }
+    };
+    fetch(0);
     for (int r = 0; r < H; ++r) {
       const int y = pass ? H - 1 - r : r;
       const int* prev = rowbuf + ((r + 1) & 1) * RW;      // previous row of this sweep (all FAR for r == 0)
       int* cur = rowbuf + (r & 1) * RW;
-      long long key[EPT];
-      for (int e = 0; e < ept; ++e) {
-        const int xs = tid * ept + e;                     // sweep column
-        long long k = 0x7FFFFFFFFFFFFFFFll;
+      int key[EPT];
+      long long lab_now[EPT];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int xs = tid * EPT + e;                     // sweep column
+        int k = 0x7FFFFFFF;
         if (xs < W) {
-          const int x = pass ? W - 1 - xs : xs;
-          int t = di[(long long)y * W + x];
+          int t = tv[e];
           const int up = sat_add(prev[xs + 1], HV), ul = sat_add(prev[xs], DG), ur = sat_add(prev[xs + 2], DG);
           t = t < up ? t : up; t = t < ul ? t : ul; t = t < ur ? t : ur;
-          k = (long long)t - (long long)HV * xs;
+          k = t - HV * xs;
         }
         key[e] = k;
+        lab_now[e] = lv[e];
       }
-      block_prefix_min(key, ept, wave_tot[r & 1]);
-      for (int e = 0; e < ept; ++e) {
-        const int xs = tid * ept + e;
+      fetch(r + 1);
+      block_prefix_min<EPT>(key, wave_tot[r & 1]);
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int xs = tid * EPT + e;
         if (xs < W) {
-          const long long dd = key[e] + (long long)HV * xs;
-          const int d = dd < FAR ? (int)dd : FAR;
+          const int dd = key[e] + HV * xs;
+          const int d = dd < FAR ? dd : FAR;
           cur[xs + 1] = d;
           const int x = pass ? W - 1 - xs : xs;
           di[(long long)y * W + x] = d;
           if (pass == 1) {
-            const long long l = li[(long long)y * W + x];
+            const long long l = lab_now[e];
             const float f = (l >= 0 && l < num_classes) ? (float)d * (1.f / 65536.f) : 0.f;
             sum += (double)f; sumsq += (double)f * (double)f;
           }
@@ -145,31 +170,43 @@ void boundary_sweep_kernel(const long long* __restrict__ lab, int* __restrict__ 
     if (var < 0.0) var = 0.0;
     float sd = (float)sqrt(var);
     if (sd == 0.f) sd = 1.f;
-    s_std = sd;
+    img_std[blockIdx.x] = sd;
   }
-  __syncthreads();
-  const float denom = 2.f * s_std;
-  const long long hw = (long long)H * W;
-  for (long long i = tid; i < hw; i += NT) {
-    const long long l = li[i];
-    const float f = (l >= 0 && l < num_classes) ? (float)di[i] * (1.f / 65536.f) : 0.f;
-    wi[i] = l == ignore_id ? 0.f : expf(-(f / denom));
+}
+
+// weight = exp(-d / (2 std)) over the whole batch (parallel; the sweep kernel only has one block per image)
+__global__ __launch_bounds__(256)
+void boundary_weight_kernel(const long long* __restrict__ lab, const int* __restrict__ dist,
+                            const float* __restrict__ img_std, float* __restrict__ weight, long long hw, long long total,
+                            int num_classes, long long ignore_id) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const long long l = lab[i];
+    const float f = (l >= 0 && l < num_classes) ? (float)dist[i] * (1.f / 65536.f) : 0.f;
+    weight[i] = l == ignore_id ? 0.f : expf(-(f / (2.f * img_std[i / hw])));
   }
 }
 
 }  // namespace
 
-extern "C" int dcs_label_boundary_weights(const int64_t* labels, int32_t* dist, float* weight, int B, int H, int W,
-                                          int num_classes, int64_t ignore_id, void* stream) {
-  DCS_CHECK_ARG(labels && dist && weight && B > 0 && H > 0 && W > 0 && num_classes > 0);
-  if (W > NT * EPT) return DCS_E_UNSUPPORTED;
+extern "C" int dcs_label_boundary_weights(const int64_t* labels, int32_t* dist, float* img_std, float* weight, int B, int H,
+                                          int W, int num_classes, int64_t ignore_id, void* stream) {
+  DCS_CHECK_ARG(labels && dist && img_std && weight && B > 0 && H > 0 && W > 0 && num_classes > 0);
+  if (W > NT * MAX_EPT) return DCS_E_UNSUPPORTED;
   hipStream_t s = dcs_stream(stream);
   const long long total = (long long)B * H * W;
   long long blocks = (total + 255) / 256;
   if (blocks > 65536) blocks = 65536;
   hipLaunchKernelGGL(boundary_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
                      reinterpret_cast<const long long*>(labels), dist, B, H, W);
-  hipLaunchKernelGGL(boundary_sweep_kernel, dim3((unsigned)B), dim3(NT), (size_t)2 * (W + 2) * sizeof(int), s,
-                     reinterpret_cast<const long long*>(labels), dist, weight, H, W, num_classes, (long long)ignore_id);
+  const size_t sh = (size_t)2 * (W + 2) * sizeof(int);
+  const long long* lp = reinterpret_cast<const long long*>(labels);
+  const int ept = (W + NT - 1) / NT;
+  if (ept <= 1)      hipLaunchKernelGGL(boundary_sweep_kernel<1>, dim3((unsigned)B), dim3(NT), sh, s, lp, dist, img_std, H, W, num_classes);
+  else if (ept <= 2) hipLaunchKernelGGL(boundary_sweep_kernel<2>, dim3((unsigned)B), dim3(NT), sh, s, lp, dist, img_std, H, W, num_classes);
+  else if (ept <= 4) hipLaunchKernelGGL(boundary_sweep_kernel<4>, dim3((unsigned)B), dim3(NT), sh, s, lp, dist, img_std, H, W, num_classes);
+  else               hipLaunchKernelGGL(boundary_sweep_kernel<8>, dim3((unsigned)B), dim3(NT), sh, s, lp, dist, img_std, H, W, num_classes);
+  hipLaunchKernelGGL(boundary_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, s,
+                     reinterpret_cast<const long long*>(labels), dist, img_std, weight, (long long)H * W, total, num_classes,
+                     (long long)ignore_id);
   DCS_LAUNCH_RET();
 }

@@ -60,7 +60,7 @@ SIGNATURES = {
     "dcs_scatter_add_rows": [_P, _P, _P, _I, _I, _P],
     "dcs_gather_rows_bilinear": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_scatter_rows_bilinear": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dcs_label_boundary_weights": [_P, _P, _P, _I, _I, _I, _I, _L, _P],
+    "dcs_label_boundary_weights": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P],
     "dcs_confusion": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_contrast_rows": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "dcs_symmetrize": [_P, _P, _I, _I, _P],

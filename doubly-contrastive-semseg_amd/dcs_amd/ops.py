@@ -640,8 +640,9 @@ def label_boundary_weights(labels, num_classes, ignore_id=255):
     B, H, W = labels.shape
     dist = torch.empty((B, H, W), device=labels.device, dtype=torch.int32)
     weight = torch.empty((B, H, W), device=labels.device, dtype=_F32)
-    _call("dcs_label_boundary_weights", _p(labels), _p(dist), _p(weight), B, H, W, int(num_classes), int(ignore_id),
-          _stream())
+    img_std = torch.empty((B,), device=labels.device, dtype=_F32)
+    _call("dcs_label_boundary_weights", _p(labels), _p(dist), _p(img_std), _p(weight), B, H, W, int(num_classes),
+          int(ignore_id), _stream())
     return weight, dist
 
 

@@ -228,9 +228,10 @@ int dcs_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float
  * labels int64 [B,H,W]; dist int32 [B,H,W] scratch -> 16.16 fixed-point 3x3 chamfer (cv2.DIST_L2, maskSize 3)
  * distance of every pixel to the nearest pixel with a different label (= the sum over classes of the per-class
  * cv2.distanceTransform values the reference computes); weight [B,H,W] = exp(-d / (2 * std_image(d))), d = 0 for
- * labels outside [0,num_classes), weight = 0 where label == ignore_id, std == 0 -> 1.  W <= 4096. */
-int dcs_label_boundary_weights(const int64_t* labels, int32_t* dist, float* weight, int B, int H, int W,
-                               int num_classes, int64_t ignore_id, void* stream);
+ * labels outside [0,num_classes), weight = 0 where label == ignore_id, std == 0 -> 1 (img_std [B] receives the
+ * per-image standard deviation).  W <= 4096. */
+int dcs_label_boundary_weights(const int64_t* labels, int32_t* dist, float* img_std, float* weight, int B, int H,
+                               int W, int num_classes, int64_t ignore_id, void* stream);
 
 /* elementwise helpers */
 int dcs_axpy(float* y, const float* x, int64_t n, float a, void* stream);           /* y += a*x */
