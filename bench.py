@@ -45,6 +45,8 @@ def parse():
     ap.add_argument("--lazy-ff0", action="store_true", help="DeepLab only: never materialise the upsampled 2048-channel "
                     "fine_feat0 (dcs_amd.losses.LazyUpsampled); same losses and gradients")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-similarity", action="store_true", help="skip the similarity-kernel measurement after the timed "
+                    "region (profiling runs: keeps the per-kernel averages to the train step's own launches)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--conv-report", default=None, help="write a per-shape conv timing table (json lines) to this file")
     return ap.parse_args()
@@ -140,7 +142,7 @@ def cpu_baseline(O, args):
 def pmc_traffic(args, world):
     """HBM bytes per conv_gather launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic_c3.json")
+    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_c3.json")
     default = (args.batch, args.height, args.width, args.criterion, args.model) == \
         (16, 1024, 2048, "supcon_pixelcontrast_focal", "resnet18")
     if not (default and os.path.exists(path)):
@@ -284,7 +286,7 @@ def main():
                        **({"lazy_fine_feat0": bool(args.lazy_ff0)} if deeplab else {})},
             "roofline": {"bound": "mfma", "achieved": g["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": g["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(args, world),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_c_pmc_traffic_c3.json)",
+                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_h_pmc_traffic_c3.json)",
                          "algorithmic_bytes_per_launch": g.get("alg_bytes_per_launch"),
                          "algorithmic_flops_per_launch": g.get("alg_flops_per_launch"),
                          "kernel": "conv_gather_kernel (conv forward + data gradient, fp32 MFMA 32x32x2)",
@@ -294,7 +296,8 @@ def main():
                                           "ms_per_step": wg["ms"] / max(args.steps, 1),
                                           "launches_per_step": wg["launches"] // max(args.steps, 1)}},
         }
-        line["similarity"] = similarity_bench(ops, dev, ts)
+        if not args.no_similarity:
+            line["similarity"] = similarity_bench(ops, dev, ts)
         if args.conv_report:
             with open(args.conv_report, "w") as f:
                 for r in prof.per_shape():
