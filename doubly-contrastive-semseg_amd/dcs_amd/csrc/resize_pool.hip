@@ -392,20 +392,34 @@ void upsample_to_nchw_bwd_kernel(const float* __restrict__ g, const float* __res
 // Separable form of the same adjoint (bilinear weights factor into wy * wx): pass 1 folds the X axis of every
 // full-resolution row, r[plane][Y][x] = sum_X wx(X,x) g[plane][Y][X]  (reads g once, coalesced along X);
 // pass 2 folds Y and transposes to NHWC through LDS so the channel-strided rows are written as whole lines.
+// `f` > 0: OW == f * IW with f a power of two.  Then an interior input column i receives exactly the 2f outputs
+// f*i - f/2 + k, k = 0..2f-1, with weights (k + 0.5)/f for k < f and (2f - k - 0.5)/f after (exact in fp32, identical
+// to what lin_src yields); border columns and other ratios take the generic scan.
 __global__ __launch_bounds__(256)
-void upsample_fold_x_kernel(const float* __restrict__ g, float* __restrict__ r, long long planes_rows, int IW, int OW) {
+void upsample_fold_x_kernel(const float* __restrict__ g, float* __restrict__ r, long long planes_rows, int IW, int OW,
+                            int f) {
   const long long total = planes_rows * IW;
   const float sx = (float)IW / (float)OW;
+  const float inv_f = f > 0 ? 1.f / (float)f : 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int ix = (int)(i % IW);
     const long long row = i / IW;
-    int xlo, xhi;
-    out_range(ix, sx, OW, xlo, xhi);
     const float* gp = g + row * OW;
     float acc = 0.f;
-    for (int ox = xlo; ox <= xhi; ++ox) {
-      const float wx = lin_w(ox, sx, IW, ix);
-      if (wx != 0.f) acc = fmaf(wx, gp[ox], acc);
+    if (f > 1 && ix > 0 && ix < IW - 1) {
+      const float* q = gp + f * ix - (f >> 1);
+      for (int k = 0; k < f; ++k) {
+        const float w = ((float)k + 0.5f) * inv_f;
+        acc = fmaf(w, q[k], acc);
+        acc = fmaf(w, q[2 * f - 1 - k], acc);
+      }
+    } else {
+      int xlo, xhi;
+      out_range(ix, sx, OW, xlo, xhi);
+      for (int ox = xlo; ox <= xhi; ++ox) {
+        const float wx = lin_w(ox, sx, IW, ix);
+        if (wx != 0.f) acc = fmaf(wx, gp[ox], acc);
+      }
     }
     r[i] = acc;
   }
@@ -548,7 +562,9 @@ extern "C" int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, flo
   if (tmp && C <= FOLD_MAXC && cs <= 2 * FOLD_MAXC && IH <= 65535 && N <= 65535) {
     // tmp: [N*C*OH*IW] floats
     const long long rows = (long long)N * C * OH;
-    hipLaunchKernelGGL(upsample_fold_x_kernel, dim3(grid_for(rows * IW, 1u << 20)), dim3(256), 0, s, g, tmp, rows, IW, OW);
+    const int fx = (OW % IW == 0 && ((OW / IW) & (OW / IW - 1)) == 0 && OW / IW <= 16) ? OW / IW : 0;
+    hipLaunchKernelGGL(upsample_fold_x_kernel, dim3(grid_for(rows * IW, 1u << 20)), dim3(256), 0, s, g, tmp, rows, IW, OW,
+                       fx);
     hipLaunchKernelGGL(upsample_fold_y_nhwc_kernel, dim3((unsigned)((IW + 255) / 256), (unsigned)IH, (unsigned)N), dim3(256),
                        (size_t)256 * cs * sizeof(float), s, tmp, gscale, gx, IH, IW, cs, C, OH);
     DCS_LAUNCH_RET();

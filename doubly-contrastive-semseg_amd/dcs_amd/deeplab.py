@@ -215,8 +215,9 @@ class DeepLabEngine:
             ff0 = out[:B] if B != Bm else out.view(out.shape)
         else:
             ff0 = ops.upsample_add(f.contiguous(), [], h, w)                   # network/utils.py:190
-        for m in self._nbt:
-            m.num_batches_tracked += 1
+        if self._nbt and not (self.flat is not None and self.flat.bump_counters(self._nbt)):
+            for m in self._nbt:
+                m.num_batches_tracked += 1
         self._nbt = []
         saved = None
         if need_grad:
@@ -435,6 +436,7 @@ class DeepLabV3(nn.Module):
 
     def flatten_parameters(self):
         flat = FlatBuffers([list(self.parameters())])       # utils/init_trainer.py:163-168: one ADAM group
+        flat.adopt_counters(self.modules())
         self._get_engine().flat = flat
         return flat
 
