@@ -222,3 +222,35 @@ def test_resume_from_checkpoint_continues_identically(tmp_path):
     assert float(oa["total"]) == float(orr["total"])
     for (k, va), vb in zip(a.model.state_dict().items(), r.model.state_dict().values()):
         assert torch.equal(va, vb), k
+
+
+def test_full_size_step_is_deterministic():
+    """BASELINE config 3 at its full size (16 labelled images x 2 crops at 2048x1024): the oracle cannot run this in
+    seconds, so the check is a size-independent property of the design -- no float atomics anywhere, fixed-order
+    reductions -- : two runs from the same state and RNG seed give bit-identical losses, sampled anchors, gradients and
+    BatchNorm statistics; everything is finite; logits gradients respect the ignore label."""
+    b, h, w = 16, 1024, 2048
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=11, two_crops=True, cell=64)
+    runs = []
+    for _ in range(2):
+        ts = build("supcon_pixelcontrast_focal", batch_size=b, cw=cw)
+        s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        torch.manual_seed(77)
+        out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
+        torch.cuda.synchronize()
+        keep = {k: out[k].detach().clone() for k in ("total", "supcon", "pixel", "seg")}
+        grads = {k: p.grad.detach().clone() for k, p in ts.model.named_parameters()
+                 if k.endswith("conv1.weight") or "segmentation" in k or "upsample_blends5" in k or k.endswith("bn1_0.weight")}
+        stats = {k: v.clone() for k, v in ts.model.state_dict().items() if "running_var" in k and ("layer1.0" in k or "bn1_" in k)}
+        runs.append((keep, grads, stats, ts.pixelcontrast_criterion.last_anchors[2].clone()))
+        del ts, out
+        torch.cuda.empty_cache()
+    (l0, g0, s0_, a0), (l1, g1, s1_, a1) = runs
+    assert all(bool(torch.isfinite(v).all()) for v in l0.values())
+    assert all(torch.equal(l0[k], l1[k]) for k in l0), {k: (float(l0[k]), float(l1[k])) for k in l0}
+    assert torch.equal(a0, a1)
+    assert len(g0) >= 10 and all(bool(torch.isfinite(v).all()) for v in g0.values())
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
+    for k in s0_:
+        assert torch.equal(s0_[k], s1_[k]), k
