@@ -914,7 +914,9 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   hipLaunchKernelGGL((conv_gather_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, \
                      *geom, accumulate, ntiles, stats)
   if (geom->stem) {
-    if (bn == 128) LAUNCH_K(128, true, 32);
+    // 14-tap stem geometry = half filter rows of 4 pixels (16 floats): 16-float chunks, 32.5 KB LDS, more blocks per CU
+    if (bn == 64 && geom->ntaps == 14) LAUNCH_K(64, true, 16);
+    else if (bn == 128) LAUNCH_K(128, true, 32);
     else if (bn == 64) LAUNCH_K(64, true, 32);
     else LAUNCH_K(32, true, 32);
   } else if (bn == 128) {

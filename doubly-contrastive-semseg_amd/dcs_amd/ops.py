@@ -9,6 +9,7 @@ All functions require CUDA(HIP) tensors; there is no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import List, Optional, Sequence, Tuple
 
@@ -119,6 +120,19 @@ def geoms_dgrad(N, IH, IW, Cin, Cout, R, S, stride, pad, dil=1):
                                    Cout, Cin))
         _geom_cache[key] = gs
     return gs
+
+
+def geom_stem_fwd(N, H, W):
+    """Forward-only variant: every filter row as two half rows of 4 pixels (14 taps of 16 floats; the 8th pixel slot of
+    the packed weight row is zero, so its data never matters)."""
+    key = ("s14", N, H, W)
+    g = _geom_cache.get(key)
+    if g is None:
+        OH, OW = out_size(H, 7, 2, 3), out_size(W, 7, 2, 3)
+        taps = [(r - 3, -3 + 4 * c, r * 32 + 16 * c) for r in range(7) for c in range(2)]
+        g = _mk_geom(N, H, W, OH, OW, OH, OW, 2, 1, 0, 0, 4, 64, taps, 224, 4, 64, stem=1)
+        _geom_cache[key] = g
+    return g
 
 
 def geom_stem(N, H, W):
@@ -271,7 +285,7 @@ def stem_conv(p, wp, want_stats=False):
     """7x7/2 pad 3 conv on the NHWC4 normalised image; wp = pack_stem_weight(conv1.weight)."""
     _req(p)
     N, H, W, _ = p.shape
-    g = geom_stem(N, H, W)
+    g = geom_stem_fwd(N, H, W) if os.environ.get("DCS_STEM14", "1") != "0" else geom_stem(N, H, W)
     y = torch.empty((N, g.DH, g.DW, 64), device=p.device, dtype=_F32)
     if not want_stats:
         _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, None, _stream())
