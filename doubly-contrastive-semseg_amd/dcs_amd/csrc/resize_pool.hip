@@ -298,32 +298,50 @@ void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ 
   }
 }
 
+// fy / fx > 0: OH == fy * IH (OW == fx * IW) with a power-of-two factor: an interior input row i then receives exactly
+// the 2f output rows f*i - f/2 + k with weights (k + 0.5)/f, k < f, mirrored after (exact in fp32 = what lin_src
+// yields); border rows / columns and other ratios take the generic scan.
 __global__ __launch_bounds__(256)
 void upsample_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int N, int IH, int IW, int OH, int OW,
-                         int C, int accumulate) {
+                         int C, int accumulate, int fy, int fx) {
   const int C4 = C >> 2;
   const long long total = (long long)N * IH * IW * C4;
   const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
+  const float inv_fy = fy > 0 ? 1.f / (float)fy : 0.f, inv_fx = fx > 0 ? 1.f / (float)fx : 0.f;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C4) * 4;
     long long q = i / C4;
     const int ix = (int)(q % IW); q /= IW;
     const int iy = (int)(q % IH);
     const int n = (int)(q / IH);
-    int ylo, yhi, xlo, xhi;
-    out_range(iy, sy, OH, ylo, yhi);
-    out_range(ix, sx, OW, xlo, xhi);
     float4 acc = make_float4(0, 0, 0, 0);
-    for (int oy = ylo; oy <= yhi; ++oy) {
-      const float wy = lin_w(oy, sy, IH, iy);
-      if (wy == 0.f) continue;
-      float4 row = make_float4(0, 0, 0, 0);
-      for (int ox = xlo; ox <= xhi; ++ox) {
-        const float wx = lin_w(ox, sx, IW, ix);
-        if (wx == 0.f) continue;
-        row = f4axpy(wx, ld4(g + (((long long)n * OH + oy) * OW + ox) * C + c), row);
+    if (fy > 1 && fx > 1 && iy > 0 && iy < IH - 1 && ix > 0 && ix < IW - 1) {
+      const float* base = g + (((long long)n * OH + (fy * iy - (fy >> 1))) * OW + (fx * ix - (fx >> 1))) * C + c;
+      for (int ky = 0; ky < 2 * fy; ++ky) {
+        const float wy = ((float)(ky < fy ? ky : 2 * fy - 1 - ky) + 0.5f) * inv_fy;
+        float4 row = make_float4(0, 0, 0, 0);
+        const float* rp = base + (long long)ky * OW * C;
+        for (int kx = 0; kx < 2 * fx; ++kx) {
+          const float wx = ((float)(kx < fx ? kx : 2 * fx - 1 - kx) + 0.5f) * inv_fx;
+          row = f4axpy(wx, ld4(rp + (long long)kx * C), row);
+        }
+        acc = f4axpy(wy, row, acc);
       }
-      acc = f4axpy(wy, row, acc);
+    } else {
+      int ylo, yhi, xlo, xhi;
+      out_range(iy, sy, OH, ylo, yhi);
+      out_range(ix, sx, OW, xlo, xhi);
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = lin_w(oy, sy, IH, iy);
+        if (wy == 0.f) continue;
+        float4 row = make_float4(0, 0, 0, 0);
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const float wx = lin_w(ox, sx, IW, ix);
+          if (wx == 0.f) continue;
+          row = f4axpy(wx, ld4(g + (((long long)n * OH + oy) * OW + ox) * C + c), row);
+        }
+        acc = f4axpy(wy, row, acc);
+      }
     }
     if (accumulate) acc = f4add(acc, ld4(gx + i * 4));
     st4(gx + i * 4, acc);
@@ -542,8 +560,9 @@ extern "C" int dcs_upsample_bwd(const float* g, float* gx, int N, int IH, int IW
                                 void* stream) {
   DCS_CHECK_ARG(g && gx && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && (C & 3) == 0);
   const long long total = (long long)N * IH * IW * (C / 4);
+  auto pow2_factor = [](int out, int in) { const int f = out / in; return (out % in == 0 && (f & (f - 1)) == 0 && f <= 16) ? f : 0; };
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), g, gx, N, IH, IW, OH, OW,
-                     C, accumulate);
+                     C, accumulate, pow2_factor(OH, IH), pow2_factor(OW, IW));
   DCS_LAUNCH_RET();
 }
 

@@ -240,8 +240,8 @@ def _with_src_cs(g, cs):
     return h
 
 
-def _nsplit(tiles, M):
-    return max(1, min(-(-1024 // tiles), -(-M // 256)))
+def _nsplit(tiles, M, blocks=1024):
+    return max(1, min(-(-blocks // tiles), -(-M // 256)))
 
 
 def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
@@ -258,7 +258,8 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
     else:
         bt = 128 if (Cout > 64 and Cin > 64) else 64
         tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
-        ns = _nsplit(tiles, M)
+        # 64-wide tiles run 4-5 blocks per CU: twice as many blocks (measured 70.6 -> 81.4 TF on 3x3/2 64->128)
+        ns = _nsplit(tiles, M, 2048 if bt == 64 else 1024)
     n = Cout * R * S * Cin
     slab = torch.empty((ns, n), device=x.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())

@@ -233,7 +233,8 @@ def test_bn_relu_maxpool_fwd_bwd(ops, N, H, W):
         close(dgd, dgr, 2e-5, "fused pool+bn dgamma"); close(dbd, dbr, 2e-5, "fused pool+bn dbeta")
 
 
-@pytest.mark.parametrize("IH,IW,OH,OW", [(4, 8, 8, 16), (3, 5, 6, 10), (2, 3, 3, 5), (1, 2, 2, 3), (5, 7, 9, 12)])
+@pytest.mark.parametrize("IH,IW,OH,OW", [(4, 8, 8, 16), (3, 5, 6, 10), (2, 3, 3, 5), (1, 2, 2, 3), (5, 7, 9, 12), (6, 9, 24, 36),
+                                         (5, 4, 10, 16)])
 def test_upsample_add_and_adjoint(ops, IH, IW, OH, OW):
     N, C = 2, 128
     x = rnd(N, IH, IW, C, seed=30)
