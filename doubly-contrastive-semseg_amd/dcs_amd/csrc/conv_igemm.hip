@@ -879,13 +879,9 @@ int check_geom(const DcsConvGeom* g) {
 // (32.5 KB LDS -> 4 blocks per CU; measured +4 % on 3x3 64->64 and +27 % on the bandwidth-bound 1x1 64->128);
 // 128-wide tiles measure the same either way and keep 32-channel chunks.  DCS_CONV_BK16 forces 16 everywhere.
 static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
-// 256-pixel tiles (DCS_CONV_BM256: 0 = never [default], 1 = 64-wide tiles only, 2 = also 128-wide tiles;
-// DCS_CONV_BM256_MIN = minimum grid size) measured the SAME as 128-pixel tiles on every C3 shape (113 / 135 TF):
-// the loss against peak is not per-tile overhead but MFMA-busy 78-89 % at a 2.0-2.35 GHz DVFS clock (PMC).
-// Also measured and dropped: a 3x3 kernel with the 6x34-pixel input halo resident in LDS (5.6x fewer A loads, 144 MFMAs
-// per wave between barriers): 3-5 % SLOWER than this per-tap kernel on every C3 shape.
-static const int g_bm256 = getenv("DCS_CONV_BM256") ? atoi(getenv("DCS_CONV_BM256")) : 0;
-static const long long g_bm256_min_tiles = getenv("DCS_CONV_BM256_MIN") ? atoll(getenv("DCS_CONV_BM256_MIN")) : 2048;
+// Measured and dropped: 256-pixel tiles (the BM template parameter; identical TFLOP/s on every C3
+// shape, so the loss against peak is not per-tile overhead but MFMA-busy 78-89 % at a 2.0-2.35 GHz DVFS clock) and a
+// 3x3 kernel with the 6x34-pixel input halo resident in LDS (3-5 % slower than this per-tap kernel).
 
 extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
                                const DcsConvGeom* geom, int accumulate, float* stats, void* stream) {
@@ -901,12 +897,7 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   // few K chunks per tile (1x1 convolutions up to 512 channels): 16-channel chunks, 3 blocks per CU, so that the
   // prologue / epilogue of one tile overlaps the main loop of two others (measured +14..18 % on those shapes)
   const bool short_k = (long long)geom->ntaps * ((geom->K + 31) / 32) <= 16;
-  // 256-pixel tiles halve the per-tile prologue/epilogue share; used when the grid still fills the chip several times
-  const long long tiles256 = (M + 255) / 256 * ntiles;
-  const bool big = !geom->stem && g_bm256 != 0 && bn >= 64 && tiles256 >= g_bm256_min_tiles &&
-                   (bn == 64 || g_bm256 >= 2) && !short_k;
-  const int bm = big ? 256 : 128;
-  const long long mtiles = (M + bm - 1) / bm;
+  const long long mtiles = (M + 127) / 128;
   const long long blocks = mtiles * ntiles;
   DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
   hipStream_t s = dcs_stream(stream);
@@ -920,12 +911,10 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
     else if (bn == 64) LAUNCH_K(64, true, 32);
     else LAUNCH_K(32, true, 32);
   } else if (bn == 128) {
-    if (big) LAUNCH_K(128, false, 16, 256);
-    else if (g_bk16 || short_k) LAUNCH_K(128, false, 16);
+    if (g_bk16 || short_k) LAUNCH_K(128, false, 16);
     else LAUNCH_K(128, false, 32);
   } else if (bn == 64) {
-    if (big) LAUNCH_K(64, false, 16, 256);
-    else LAUNCH_K(64, false, 16);
+    LAUNCH_K(64, false, 16);
   } else {
     LAUNCH_K(32, false, 32);
   }
