@@ -254,3 +254,52 @@ def test_full_size_step_is_deterministic():
         assert torch.equal(g0[k], g1[k]), k
     for k in s0_:
         assert torch.equal(s0_[k], s1_[k]), k
+
+
+def test_reference_style_loop_with_torch_adam_matches_trainstep():
+    """The drop-in scenario of INTEGRATION.md: the reference's own trainer keeps ITS optimizer (torch.optim.Adam built at
+    utils/init_trainer.py:169-177), calls zero_grad / backward / step itself (trainer.py:212-214) and never flattens the
+    parameters.  Two such steps must land on the same parameters as TrainStep's flat fused-Adam path."""
+    from dcs_amd.losses import BoundaryAwareFocalLoss, PixelContrastLoss
+    from dcs_amd.model import WeatherNet
+    from dcs_amd.trainer import make_opts
+    b, h, w = 2, 128, 256
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=13, cell=32)
+    ts = build("pixelcontrast_focal", batch_size=b, cw=cw)
+    opts = make_opts(criterion="pixelcontrast_focal", batch_size=b)
+    opts.weight = cw
+    model = WeatherNet(opts, num_classes=19, device=torch.device(DEV), backbone="resnet18", train_semantic=True).to(DEV)
+    model.load_state_dict(O.make_state(seed=1), strict=True)
+    model.train()
+    crit = BoundaryAwareFocalLoss(gamma=0.5, num_classes=19, ignore_id=255, weight=cw, device=torch.device(DEV), opts=opts)
+    pixc = PixelContrastLoss(device=torch.device(DEV))
+    optim = torch.optim.Adam([{"params": model.random_init_params(), "lr": opts.lr, "weight_decay": opts.weight_decay},
+                              {"params": model.fine_tune_params(), "lr": opts.lr / 4, "weight_decay": opts.weight_decay / 4}],
+                             betas=(0.9, 0.99))
+    for it in range(2):
+        sample = dict(left=img, label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        torch.manual_seed(40 + it)
+        out = ts.step(sample)
+        # ---- trainer.py:62-215, reference style ----
+        left = img.to(DEV)
+        lab = labels.clone().to(DEV)
+        torch.manual_seed(40 + it)
+        left_seg, before, fine_feat, fine_feat0 = model(left, return_supcon_feature=False)
+        pix = pixc(fine_feat0, labels=lab, predict=before)
+        seg = crit(left_seg, lab, dict(label_distance_weight=ldw))
+        total = pix * 1 / opts.batch_size + seg * 1.2
+        optim.zero_grad()
+        total.backward()
+        optim.step()
+        assert abs(float(total) - float(out["total"])) <= 1e-6 * abs(float(out["total"])), (it, float(total), float(out["total"]))
+    # Adam's first steps move every weight by ~lr * g / |g|: single elements whose gradient is at rounding level may
+    # take a different direction, so the UPDATES are compared in relative L2
+    p0 = O.make_state(seed=1)
+    for (k, pa), pb in zip(ts.model.named_parameters(), model.parameters()):
+        ua, ub = pa.detach().cpu() - p0[k], pb.detach().cpu() - p0[k]
+        assert float((ua - ub).norm()) <= 2e-2 * float(ua.norm()) + 1e-9, (k, float((ua - ub).norm()), float(ua.norm()))
+    for (k, va), vb in zip(ts.model.state_dict().items(), model.state_dict().values()):
+        if "num_batches" in k:
+            assert torch.equal(va, vb), k
+        elif "running" in k:
+            close(vb, va.cpu(), 1e-5, k)
