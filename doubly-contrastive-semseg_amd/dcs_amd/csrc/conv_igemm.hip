@@ -328,17 +328,18 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
 // weight gradient: dW[co][tap][ci] = sum_m dy[m][co] * src[gather(m,tap)][ci]
 // Block = one (tap, co tile, ci tile) and one pixel range (split); pixels are the GEMM K dimension,
 // staged 32 at a time as [pixel][channel] rows, read column-wise by conflict-free ds_read_b32.
-template <int BT>
-__global__ __launch_bounds__(256, 2)
+template <int BT, int CH = 32>
+__global__ __launch_bounds__(256, (BT == 128 && CH == 16) ? 4 : 2)
 void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                        const DcsConvGeom g, const int dy_cstride, const int split0, const long long mps,
                        const int ciT) {
   constexpr int T = BT / 64;          // 32x32 tiles per wave per dim
   constexpr int C4 = BT / 4;          // float4 per staged row
   constexpr int RP = 256 / C4;        // rows per load pass
-  constexpr int NP = 32 / RP;         // passes per chunk
-  __shared__ __attribute__((aligned(16))) float Ds[2][32 * BT];
-  __shared__ __attribute__((aligned(16))) float Xs[2][32 * BT];
+  constexpr int NP = CH / RP;         // passes per chunk (CH = pixels per chunk: 32, or 16 -> half the LDS)
+  static_assert(NP >= 1, "chunk too small for this tile");
+  __shared__ __attribute__((aligned(16))) float Ds[2][CH * BT];
+  __shared__ __attribute__((aligned(16))) float Xs[2][CH * BT];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
@@ -400,8 +401,8 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
         off = (((p_n[i] - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride;
       }
       rx[i] = bld4(rsX, ok ? (unsigned)off * 4u : OOB);
-      // advance this slot by 32 pixels
-      p_tx[i] += 32;
+      // advance this slot by one chunk of pixels
+      p_tx[i] += CH;
       while (p_tx[i] >= g.TX) { p_tx[i] -= g.TX; p_ty[i] += 1; }
       while (p_ty[i] >= g.TY) { p_ty[i] -= g.TY; p_n[i] += 1; }
     }
@@ -422,7 +423,7 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  const long long nch = mend > mbeg ? (mend - mbeg + 31) / 32 : 0;
+  const long long nch = mend > mbeg ? (mend - mbeg + CH - 1) / CH : 0;
   if (nch > 0) {
     load_chunk(mbeg);
     store_chunk(0);
@@ -431,11 +432,11 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
   for (long long ch = 0; ch < nch; ++ch) {
     const int buf = (int)(ch & 1);
     const bool more = ch + 1 < nch;
-    if (more) load_chunk(mbeg + (ch + 1) * 32);
+    if (more) load_chunk(mbeg + (ch + 1) * CH);
     const float* Db = &Ds[buf][wm * (BT / 2) + l31];
     const float* Xb = &Xs[buf][wn * (BT / 2) + l31];
 #pragma unroll
-    for (int kk = 0; kk < 32; kk += 8) {
+    for (int kk = 0; kk < CH; kk += 8) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int row = kk + 4 * h + j;
@@ -922,6 +923,10 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   DCS_LAUNCH_RET();
 }
 
+// 128-wide generic weight-gradient tiles stage 16 pixels per chunk (32 KB LDS, 4 blocks per CU): +4..9 % over 32-pixel
+// chunks at 2 blocks per CU on the 1x1 layers (the kernel is stall-bound, not MFMA-bound).  DCS_WGRAD_CH32 restores 32.
+static const bool g_wgrad_ch16 = getenv("DCS_WGRAD_CH32") == nullptr;
+
 extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom,
                               int dy_cstride, int split0, int nsplit, void* stream) {
   int rc = check_geom(geom);
@@ -965,7 +970,10 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
   hipStream_t s = dcs_stream(stream);
   dim3 grid((unsigned)(geom->ntaps * coT * ciT), (unsigned)nsplit);
   if (bt == 128)
-    hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
+    if (g_wgrad_ch16)
+      hipLaunchKernelGGL((conv_wgrad_kernel<128, 16>), grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
+    else
+      hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
   else
     hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
   DCS_LAUNCH_RET();
