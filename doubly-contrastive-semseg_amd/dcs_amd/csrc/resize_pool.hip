@@ -424,7 +424,15 @@ void upsample_fold_x_kernel(const float* __restrict__ g, float* __restrict__ r, 
     const long long row = i / IW;
     const float* gp = g + row * OW;
     float acc = 0.f;
-    if (f > 1 && ix > 0 && ix < IW - 1) {
+    if (f == 4 && ix > 0 && ix < IW - 1) {
+      // the 8 outputs 4*ix-2 .. 4*ix+5 out of three ALIGNED 16-byte loads (whole cache lines per wave instead of eight
+      // 4-byte loads at a 16-byte lane stride)
+      const float4 a0 = ld4(gp + 4 * ix - 4), a1 = ld4(gp + 4 * ix), a2 = ld4(gp + 4 * ix + 4);
+      acc = 0.125f * (a0.z + a2.y);
+      acc = fmaf(0.375f, a0.w + a2.x, acc);
+      acc = fmaf(0.625f, a1.x + a1.w, acc);
+      acc = fmaf(0.875f, a1.y + a1.z, acc);
+    } else if (f > 1 && ix > 0 && ix < IW - 1) {
       const float* q = gp + f * ix - (f >> 1);
       for (int k = 0; k < f; ++k) {
         const float w = ((float)k + 0.5f) * inv_f;
@@ -581,7 +589,8 @@ extern "C" int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, flo
   if (tmp && C <= FOLD_MAXC && cs <= 2 * FOLD_MAXC && IH <= 65535 && N <= 65535) {
     // tmp: [N*C*OH*IW] floats
     const long long rows = (long long)N * C * OH;
-    const int fx = (OW % IW == 0 && ((OW / IW) & (OW / IW - 1)) == 0 && OW / IW <= 16) ? OW / IW : 0;
+    int fx = (OW % IW == 0 && ((OW / IW) & (OW / IW - 1)) == 0 && OW / IW <= 16) ? OW / IW : 0;
+    if (fx == 4 && !dcs_aligned16(g)) fx = 0;            // the x4 path uses aligned 16-byte loads
     hipLaunchKernelGGL(upsample_fold_x_kernel, dim3(grid_for(rows * IW, 1u << 20)), dim3(256), 0, s, g, tmp, rows, IW, OW,
                        fx);
     hipLaunchKernelGGL(upsample_fold_y_nhwc_kernel, dim3((unsigned)((IW + 255) / 256), (unsigned)IH, (unsigned)N), dim3(256),
