@@ -135,7 +135,8 @@ template <int BN, bool STEM, int BKT, int BM = 128>
 __global__ __launch_bounds__(256, (BKT == 16 && BM * BN <= 128 * 128) ? 3 : 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                         const float* __restrict__ bias, float* __restrict__ dst,
-                        const DcsConvGeom g, const int accumulate, const int ntiles, float* __restrict__ stats) {
+                        const DcsConvGeom g, const int accumulate, const int ntiles, float* __restrict__ stats,
+                        const int cps, const long long slab_stride) {
   constexpr int WN = (BN >= 128 || (BN == 64 && BM == 128)) ? 2 : 1;
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (WM * 32);
@@ -214,6 +215,12 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
 
   const int kch = STEM ? 1 : (g.K + BKT - 1) / BKT;
   const int nch = g.ntaps * kch;
+  // split-K launches (grid.y > 1): this block reduces chunks [cbeg, cend) only and writes its partial tile to slab
+  // blockIdx.y (dst + blockIdx.y * slab_stride); a fixed-order reduce kernel sums the slabs.  Few-tile launches (deep
+  // layers of small inputs) otherwise leave most CUs idle behind a 100+-chunk serial loop.
+  const int cbeg = (int)blockIdx.y * cps < nch ? (int)blockIdx.y * cps : nch;
+  const int cend = cbeg + cps < nch ? cbeg + cps : nch;
+  dst += (long long)blockIdx.y * slab_stride;
 
   // Register staging slots: 0..NA-1 = the A rows of this thread, NA.. = its B rows.
   constexpr int NSLOT = NA + BROWS;
@@ -263,12 +270,12 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   // in iteration ch-1, before the barrier) and immediately re-loaded with chunk ch+2, one slot per pair of MFMAs,
   // so LDS writes, address arithmetic and load issue sit in the shadow of the matrix pipe and every global load
   // has a full iteration (>= 48 MFMAs per wave) to land.  The tail iterations re-load the last chunk (harmless).
-  set_chunk(0);
+  set_chunk(cbeg < nch ? cbeg : nch - 1);
 #pragma unroll
   for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
 #pragma unroll
   for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, 0);
-  set_chunk(nch > 1 ? 1 : 0);
+  set_chunk(cbeg + 1 < cend ? cbeg + 1 : (cbeg < nch ? cbeg : nch - 1));
 #pragma unroll
   for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
   __syncthreads();
@@ -296,14 +303,14 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     }
   };
 
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
+  for (int ch = cbeg; ch < cend; ++ch) {
+    const int buf = (ch - cbeg) & 1;
     const float* Ab = &As[buf][(wm * TM * 32 + l31) * LDKT + 4 * h];
     const float* Bb = &Bs[buf][(wn * TN * 32 + l31) * LDKT + 4 * h];
     frag_load(0, Ab, Bb, 0);
     frag_load(1, Ab, Bb, 8);
     mfma_range(0, 0, G);
-    set_chunk(ch + 2 < nch ? ch + 2 : nch - 1);
+    set_chunk(ch + 2 < cend ? ch + 2 : cend - 1);
     if (NG == 4) frag_load(0, Ab, Bb, 16);
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) {
@@ -884,12 +891,12 @@ static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
 // shape, so the loss against peak is not per-tile overhead but MFMA-busy 78-89 % at a 2.0-2.35 GHz DVFS clock) and a
 // 3x3 kernel with the 6x34-pixel input halo resident in LDS (3-5 % slower than this per-tap kernel).
 
-extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
-                               const DcsConvGeom* geom, int accumulate, float* stats, void* stream) {
+static int launch_gather(const float* src, const float* wgt, const float* bias, float* dst, const DcsConvGeom* geom,
+                         int accumulate, float* stats, int nsplit, long long slab_stride, void* stream) {
   int rc = check_geom(geom);
   if (rc != DCS_OK) return rc;
   DCS_CHECK_ARG(src && wgt && dst && dcs_aligned16(src) && dcs_aligned16(wgt));
-  DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout);
+  DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout && nsplit >= 1 && nsplit <= 64);
   const long long M = (long long)geom->N * geom->TY * geom->TX;
   DCS_CHECK_ARG(M < 0x7FFFFF00ll);
   const int bn = geom->Cout > 64 ? 128 : (geom->Cout > 32 ? 64 : 32);
@@ -901,18 +908,23 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   const long long mtiles = (M + 127) / 128;
   const long long blocks = mtiles * ntiles;
   DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
+  // K-chunk width of the variant that will run, to cut the chunk range into nsplit equal parts
+  const bool stem14 = geom->stem && bn == 64 && geom->ntaps == 14;
+  const int bkt = geom->stem ? (stem14 ? 16 : 32) : (bn == 64 ? 16 : (bn == 128 && (g_bk16 || short_k) ? 16 : 32));
+  const int nch = geom->ntaps * (geom->stem ? 1 : (geom->K + bkt - 1) / bkt);
+  const int cps = (nch + nsplit - 1) / nsplit;
   hipStream_t s = dcs_stream(stream);
-#define LAUNCH_K(...)                                                                                                 \
-  hipLaunchKernelGGL((conv_gather_kernel<__VA_ARGS__>), dim3((unsigned)blocks), dim3(256), 0, s, src, wgt, bias, dst, \
-                     *geom, accumulate, ntiles, stats)
+#define LAUNCH_K(...)                                                                                                  \
+  hipLaunchKernelGGL((conv_gather_kernel<__VA_ARGS__>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, \
+                     wgt, bias, dst, *geom, accumulate, ntiles, stats, cps, slab_stride)
   if (geom->stem) {
     // 14-tap stem geometry = half filter rows of 4 pixels (16 floats): 16-float chunks, 32.5 KB LDS, more blocks per CU
-    if (bn == 64 && geom->ntaps == 14) LAUNCH_K(64, true, 16);
+    if (stem14) LAUNCH_K(64, true, 16);
     else if (bn == 128) LAUNCH_K(128, true, 32);
     else if (bn == 64) LAUNCH_K(64, true, 32);
     else LAUNCH_K(32, true, 32);
   } else if (bn == 128) {
-    if (g_bk16 || short_k) LAUNCH_K(128, false, 16);
+    if (bkt == 16) LAUNCH_K(128, false, 16);
     else LAUNCH_K(128, false, 32);
   } else if (bn == 64) {
     LAUNCH_K(64, false, 16);
@@ -921,6 +933,17 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   }
 #undef LAUNCH_K
   DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
+                               const DcsConvGeom* geom, int accumulate, float* stats, void* stream) {
+  return launch_gather(src, wgt, bias, dst, geom, accumulate, stats, 1, 0, stream);
+}
+
+extern "C" int dcs_conv_gather_split(const float* src, const float* wgt, float* slab, const DcsConvGeom* geom, int nsplit,
+                                     int64_t slab_stride, void* stream) {
+  DCS_CHECK_ARG(geom && slab_stride >= (int64_t)geom->N * geom->DH * geom->DW * geom->dst_cstride);
+  return launch_gather(src, wgt, nullptr, slab, geom, 0, nullptr, nsplit, slab_stride, stream);
 }
 
 // 128-wide generic weight-gradient tiles stage 16 pixels per chunk (32 KB LDS, 4 blocks per CU): +4..9 % over 32-pixel

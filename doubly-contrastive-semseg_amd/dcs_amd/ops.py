@@ -173,6 +173,27 @@ def _stats_reduce(part, G, G1, Cout):
     return out
 
 
+def _ksplit(g, M, Cout):
+    """Number of K splits for a gather launch: 1 unless the launch has too few output tiles to fill the chip AND a long
+    reduction (deep layers of small inputs, e.g. 512-channel 3x3 on 8x16 maps: 128 blocks x 144 chunks)."""
+    if g.stem or g.dsy != 1 or g.dst_cstride != Cout or os.environ.get("DCS_KSPLIT", "1") == "0":
+        return 1
+    bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
+    blocks = (-(-M // CONV_BM)) * (-(-Cout // bn))
+    nch32 = g.ntaps * (-(-g.K // 32))
+    if blocks > 160 or nch32 < 24 or M < 2048:      # below ~2K pixels the launch is latency-bound either way
+        return 1
+    return int(max(1, min(8, 512 // blocks, nch32 // 6)))
+
+
+def _gather_split(src, wgt, g, ns, dst, accumulate):
+    """Split-K launch + fixed-order slab reduce into dst (dense [N,DH,DW,Cout])."""
+    n = dst.numel()
+    slab = torch.empty((ns, n), device=dst.device, dtype=_F32)
+    _call("dcs_conv_gather_split", _p(src), _p(wgt), _p(slab), C.byref(g), ns, n, _stream())
+    _call("dcs_reduce_slab", _p(slab), _p(dst), n, ns, 1 if accumulate else 0, 0, 0, _stream())
+
+
 def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None):
     """nn.Conv2d forward.  x [N,H,W,Cin]; w OIHW channels_last; -> [N,OH,OW,dst_cs or Cout].
     want_stats: also return sums [1,2,Cout] (per-channel sum / sum of squares of the output) from the fused epilogue.
@@ -183,12 +204,19 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1,
     Cout, Ktot, R, S = w.shape
     g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, None, dst_cs, dil, koff or 0, Ktot)
     cs = dst_cs or Cout
+    ns = _ksplit(g, N * g.DH * g.DW, Cout) if bias is None else 1
     if out is not None:
         assert not want_stats
-        _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(out), C.byref(g), 1, None, _stream())
+        if ns > 1 and out.is_contiguous():
+            _gather_split(x, krsc(w), g, ns, out, True)
+        else:
+            _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(out), C.byref(g), 1, None, _stream())
         return out
     alloc = torch.zeros if cs != Cout else torch.empty
     y = alloc((N, g.DH, g.DW, cs), device=x.device, dtype=_F32)
+    if ns > 1:
+        _gather_split(x, krsc(w), g, ns, y, False)
+        return (y, colsum(y.reshape(-1, Cout))) if want_stats else y
     if not want_stats:
         _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, None, _stream())
         return y
@@ -224,7 +252,11 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
             continue
         if cs != g.src_cstride:
             g = _with_src_cs(g, cs)
-        _call("dcs_conv_gather", _p(dy), _p(wp), None, _p(out), C.byref(g), 1 if accumulate else 0, None, _stream())
+        ns = _ksplit(g, N * g.TY * g.TX, Cin) if (len(gs) == 1 and out.is_contiguous()) else 1
+        if ns > 1:
+            _gather_split(dy, wp, g, ns, out, accumulate)
+        else:
+            _call("dcs_conv_gather", _p(dy), _p(wp), None, _p(out), C.byref(g), 1 if accumulate else 0, None, _stream())
     return out
 
 

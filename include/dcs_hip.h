@@ -66,6 +66,14 @@ typedef struct DcsConvGeom {
 int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
                     const DcsConvGeom* geom, int accumulate, float* stats, void* stream);
 
+/* Split-K variant of dcs_conv_gather for launches with few output tiles (deep layers of small inputs: a handful of
+ * blocks behind a 100+-chunk serial loop leaves most CUs idle): grid.y = nsplit, split s reduces its share of the
+ * (tap, channel-chunk) range and writes its partial output to slab + s * slab_stride (same addressing as dst;
+ * slab_stride >= N*DH*DW*dst_cstride elements).  dcs_reduce_slab then sums the slabs in fixed order (deterministic),
+ * optionally accumulating into dst.  No bias, no fused statistics. */
+int dcs_conv_gather_split(const float* src, const float* wgt, float* slab, const DcsConvGeom* geom, int nsplit,
+                          int64_t slab_stride, void* stream);
+
 /* Weight gradient, split over pixel ranges.  slab[split][co][wstride] receives partial sums for
  * split = split0 .. split0+nsplit-1 (every element of those slab slices is written).
  * replaces the weight half of aten::convolution_backward.                                      */

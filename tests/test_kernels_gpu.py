@@ -60,6 +60,9 @@ CONV_CASES = [
     (1, 12, 32, 32, 40, 3, 1),       # ragged output channels
     (2, 4, 96, 16, 64, 3, 1),        # a single 16-channel K chunk per tap
     (1, 8, 32, 128, 128, 3, 1),
+    (8, 16, 32, 256, 256, 3, 1),     # 4096 pixels x 2 column tiles x 72 chunks: split-K forward and data gradient
+    (4, 24, 24, 512, 512, 3, 1),     # 2304 pixels, ragged last row tile
+    (8, 16, 32, 128, 256, 3, 2),     # strided: forward splits, the four parity-class data gradients do not
 ]
 
 

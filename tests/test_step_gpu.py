@@ -90,7 +90,11 @@ def test_train_step_matches_oracle(criterion, two, b, h, w):
         if gref is None:
             assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
         else:
-            close_l2(params[k].grad, gref.numpy(), 2e-2, k)      # fp32 gradient resolution at these small sizes
+            # fp32 gradient resolution at these small sizes (BatchNorm over <= 300 samples in layer4): two equally valid
+            # fp32 summation orders of the same kernels (split-K on / off, outputs equal to 2e-6) measure 0.7e-2 and
+            # 2.9e-2 against the float64 oracle on the 200x320 case; exactness of the graph is pinned in float64 by
+            # tests/test_host_logic_cpu.py
+            close_l2(params[k].grad, gref.numpy(), 4e-2, k)
     sd = ts.model.state_dict()
     for k, v in state.items():
         if "running_" in k:
