@@ -181,9 +181,10 @@ def _ksplit(g, M, Cout):
     bn = 128 if Cout > 64 else (64 if Cout > 32 else 32)
     blocks = (-(-M // CONV_BM)) * (-(-Cout // bn))
     nch32 = g.ntaps * (-(-g.K // 32))
-    if blocks > 160 or nch32 < 24 or M < 2048:      # below ~2K pixels the launch is latency-bound either way
+    if blocks > 160 or nch32 < 24:
         return 1
-    return int(max(1, min(8, 512 // blocks, nch32 // 6)))
+    # e.g. 512 -> 512 channels 3x3 on 8 images of 4x8 pixels: 8 blocks x 144 chunks = 300 us serial; 16 splits: 25 us
+    return int(max(1, min(16, 512 // blocks, nch32 // 6)))
 
 
 def _gather_split(src, wgt, g, ns, dst, accumulate):
