@@ -287,7 +287,8 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
     M = N * g.DH * g.DW
     if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 32 == 0:
         tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
-        ns = max(1, min(-(-1024 // tiles), M // 32))      # 1024 blocks = 2 full rounds of 2 blocks per CU
+        # 1024 blocks = 2 full rounds of 2 blocks per CU, but at least 8 chunks of 32 pixels per block (small inputs)
+        ns = max(1, min(-(-1024 // tiles), (M // 32) // 8))
     else:
         bt = 128 if (Cout > 64 and Cin > 64) else 64
         tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
