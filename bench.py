@@ -279,12 +279,15 @@ def main():
         g = ps.get("dcs_conv_gather", dict(tflops=0.0, avg_us=0.0, launches=0, ms=0.0))
         wg = ps.get("dcs_conv_wgrad", dict(tflops=0.0, avg_us=0.0, launches=0, ms=0.0))
         crops = 2 if two else 1
+        key = (b, args.height, args.width, args.criterion)
+        cfg_name = {(16, 1024, 2048, "supcon_pixelcontrast_focal"): "C3" if world == 1 else "C4",
+                    (8, 512, 1024, "pixelcontrast_focal"): "C2"}.get(key, "custom")
         line = {
             "metric": "images/sec (2048x1024) " + ("DeepLabV3+-RN101" if deeplab else "SwiftNet-RN18") + " train step",
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"C5: DeepLabV3+ RN101 (OS16)" if deeplab else "C3: SwiftNet-RN18 pyramid") +
+            "config": {"workload": (f"C5: DeepLabV3+ RN101 (OS16)" if deeplab else cfg_name + ": SwiftNet-RN18 pyramid") +
                                    f" + {args.criterion}, B={b}/GPU labelled images x {crops} crops "
                                    f"at {args.width}x{args.height}, fwd+losses+bwd+Adam",
                        "global_batch": b * world, "crops_per_image": crops, "parallelism": f"dp{world}",
