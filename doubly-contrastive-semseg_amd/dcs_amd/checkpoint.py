@@ -47,11 +47,32 @@ def save_checkpoint(state, path):
     torch.save(state, path, _use_new_zipfile_serialization=False)
 
 
+def _numpy_scalar_globals():
+    """The reference stores ``score`` = Evaluator.get_results() (a dict of numpy float64 scalars / arrays) and
+    ``best_score`` = score['Mean IoU'] (np.float64) in its checkpoints (trainer.py:383, :393-399, :413-423).  The
+    weights-only unpickler rebuilds them only when numpy's scalar / array reconstructors and dtype classes are
+    allow-listed; nothing else from the file can run."""
+    import numpy as np
+    try:
+        from numpy._core import multiarray as _ma
+    except ImportError:                                  # numpy < 2
+        from numpy.core import multiarray as _ma
+    names = ("float64", "float32", "float16", "int64", "int32", "int16", "int8", "uint8", "uint16", "uint32", "uint64",
+             "bool")
+    return [_ma.scalar, _ma._reconstruct, np.ndarray, np.dtype] + sorted({type(np.dtype(n)) for n in names}, key=repr)
+
+
+def safe_load(path, map_location=None):
+    """torch.load(weights_only=True) that also accepts numpy scalars / arrays (see _numpy_scalar_globals)."""
+    with torch.serialization.safe_globals(_numpy_scalar_globals()):
+        return torch.load(path, map_location=map_location or "cpu", weights_only=True)
+
+
 def load_checkpoint(path, model, optimizer=None, continue_training=False, map_location=None):
     """utils/init_trainer.py:246-279.  Returns the bookkeeping fields (empty unless ``continue_training``)."""
     if not os.path.isfile(path):
         raise RuntimeError("=> no checkpoint found at '{}'".format(path))
-    ckpt = torch.load(path, map_location=map_location or "cpu", weights_only=True)
+    ckpt = safe_load(path, map_location)
     loaded = ckpt["model_state"]
     model_dict = model.state_dict()
     model_dict.update({k: v for k, v in loaded.items() if k in model_dict})

@@ -899,6 +899,18 @@ static int launch_gather(const float* src, const float* wgt, const float* bias, 
   DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout && nsplit >= 1 && nsplit <= 64);
   const long long M = (long long)geom->N * geom->TY * geom->TX;
   DCS_CHECK_ARG(M < 0x7FFFFF00ll);
+  // 32-bit buffer addressing inside the kernel: source offsets are relative to the first image a block touches and a
+  // block's 128 (or, for K splits, the same 128) output pixels may reach into the following image(s); the weight
+  // tensor is addressed from its base.  Both windows must stay below 2 GiB (num_records is a 31-bit byte count and
+  // offsets >= 2^31 mean "out of range -> 0"), otherwise the kernel would silently read zeros.
+  {
+    const long long tyx = (long long)geom->TY * geom->TX;
+    const long long img_bytes = (long long)geom->SH * geom->SW * geom->src_cstride * 4;
+    long long span = 127 / tyx + 2;                       // images a 128-pixel block can touch
+    if (span > geom->N) span = geom->N;
+    if (span * img_bytes > 0x7FFFFFFFll || (long long)geom->Cout * geom->wstride * 4 > 0x7FFFFFFFll)
+      return DCS_E_UNSUPPORTED;
+  }
   const int bn = geom->Cout > 64 ? 128 : (geom->Cout > 32 ? 64 : 32);
   const int ntiles = (geom->Cout + bn - 1) / bn;
   DCS_CHECK_ARG(!(stats && accumulate));

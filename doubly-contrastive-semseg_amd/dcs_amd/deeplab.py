@@ -111,8 +111,15 @@ class DeepLabEngine:
         self._seed = 0
 
     def _galloc(self, p):
+        """Gradient destination of parameter p: its view of the flat gradient buffer, unless ``p.grad`` already IS
+        that view (an earlier backward wrote it and nobody reset it to None): autograd semantics are then to ADD,
+        so the engine writes to a scratch tensor that autograd accumulates (gradient accumulation over micro-batches,
+        zero_grad(set_to_none=False), and the segmentation head, which is in no ADAM group -- SURVEY.md N1 -- and
+        therefore never reset by ``optimizer.zero_grad()``, exactly like in the reference)."""
         v = self.flat.grad_view.get(p) if self.flat is not None else None
-        return v if v is not None else torch.empty_like(p)
+        if v is not None and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+            return v
+        return torch.empty_like(p)
 
     def _bn(self, x, m, training, rows=None, sums=None):
         Cc = x.shape[-1]
@@ -398,8 +405,8 @@ class _DeepLabFn(torch.autograd.Function):
         g_seg = g_seg.contiguous() if g_seg is not None else None
         g_ff = g_ff.contiguous() if g_ff is not None else None
         grads = ctx.engine.backward(ctx.saved, g_seg, g_before, g_ff, g_ff0)
-        ctx.saved = None
         flat = ctx.engine.flat
+        ctx.saved = None
         res = []
         for p in ctx.params:
             gp = grads.get(p)

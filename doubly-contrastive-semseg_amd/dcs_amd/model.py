@@ -203,8 +203,15 @@ class SwiftNetEngine:
         self.flat: Optional[FlatBuffers] = None
 
     def _galloc(self, p):
+        """Gradient destination of parameter p: its view of the flat gradient buffer, unless ``p.grad`` already IS
+        that view (an earlier backward wrote it and nobody reset it to None): autograd semantics are then to ADD,
+        so the engine writes to a scratch tensor that autograd accumulates (gradient accumulation over micro-batches,
+        zero_grad(set_to_none=False), and the segmentation head, which is in no ADAM group -- SURVEY.md N1 -- and
+        therefore never reset by ``optimizer.zero_grad()``, exactly like in the reference)."""
         v = self.flat.grad_view.get(p) if self.flat is not None else None
-        return v if v is not None else torch.empty_like(p)
+        if v is not None and (p.grad is None or p.grad.data_ptr() != v.data_ptr()):
+            return v
+        return torch.empty_like(p)
 
     # ---- helpers ---------------------------------------------------------
     def _bn(self, x, m: nn.BatchNorm2d, training, rows=None, sums=None):
@@ -485,8 +492,8 @@ class _SwiftNetFn(torch.autograd.Function):
             g_seg = g_seg.contiguous()
         grads = ctx.engine.backward(ctx.saved, g_seg if ctx.has[0] else None,
                                     g_before if (ctx.has[1] and g_before is not None) else None, g_ff)
-        ctx.saved = None
         flat = ctx.engine.flat
+        ctx.saved = None
         res = []
         for p in ctx.params:
             gp = grads.get(p)

@@ -168,6 +168,8 @@ class TrainStep:
                 {"params": list(self.model.fine_tune_params()), "lr": opts.lr / fine_tune_factor,
                  "weight_decay": opts.weight_decay / fine_tune_factor}]
         self.optimizer = DcsAdam(groups, betas=(0.9, 0.99), flat=self.flat)
+        owned = {id(p) for g in groups for p in g["params"]}
+        self._unowned = [p for p in self.model.parameters() if id(p) not in owned]
         self.num_iter = 0
         self.model.train()
 
@@ -233,6 +235,11 @@ class TrainStep:
             total = out["seg"]
         self.optimizer.zero_grad()
         self.supcon_criterion.zero_grad()
+        # parameters in no ADAM group (the segmentation head): the reference never resets their .grad
+        # (it accumulates unused for the whole run); here they are reset so that the gradient lands in the flat buffer
+        # directly and the data-parallel all-reduce never re-reduces an old sum
+        for p in self._unowned:
+            p.grad = None
         total.backward()
         if do_optimizer_step:
             self.optimizer.step()

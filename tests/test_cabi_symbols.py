@@ -50,3 +50,28 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(lib, "LIB_PATH", "/nonexistent/libdcs_hip.so")
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         lib.load()
+
+
+def test_conv_gather_refuses_windows_beyond_32bit_addressing():
+    """conv_gather_kernel addresses its source relative to the first image of a block and the weights from their base
+    with 32-bit byte offsets (hardware range-checked buffer loads).  A geometry whose two-image window or weight tensor
+    exceeds 2 GiB - 1 must come back as DCS_E_UNSUPPORTED from the launcher -- the check precedes the launch, so no GPU
+    (and no allocation: the pointers are never dereferenced) is needed.  Mirrors the check in dcs_conv_wgrad."""
+    import ctypes as C
+    from dcs_amd import lib, ops
+    l = lib.load()
+    fake = C.c_void_p(0x100000)                         # 16-byte aligned, never dereferenced
+    # 1x1 convolution on 2 images of 2048 channels x 600 x 600: one image = 2.95 GB
+    big = ops.geom_fwd(2, 600, 600, 2048, 64, 1, 1, 1, 0)
+    assert l.dcs_conv_gather(fake, fake, None, fake, C.byref(big), 0, None, None) == -3
+    assert l.dcs_conv_gather_split(fake, fake, fake, C.byref(big), 2, 2 * 600 * 600 * 64, None) == -3
+    # one image fits (1.47 GB) but a block's 128 pixels straddle two images only if N > 1
+    one = ops.geom_fwd(1, 424, 424, 2048, 64, 1, 1, 1, 0)
+    two = ops.geom_fwd(2, 424, 424, 2048, 64, 1, 1, 1, 0)
+    assert l.dcs_conv_gather(fake, fake, None, fake, C.byref(two), 0, None, None) == -3
+    assert l.dcs_conv_gather(fake, fake, None, fake, C.byref(one), 0, None, None) != -3   # passes the check (-2 w/o GPU)
+    # weights beyond 2 GiB: 16384 -> 16384 channels 3x3
+    wide = ops.geom_fwd(1, 8, 8, 16384, 16384, 3, 3, 1, 1)
+    assert l.dcs_conv_gather(fake, fake, None, fake, C.byref(wide), 0, None, None) == -3
+    with pytest.raises(RuntimeError, match="DCS_E_UNSUPPORTED"):
+        lib.check(-3, "dcs_conv_gather")

@@ -141,3 +141,34 @@ def test_engine_matches_oracle_fp64_odd_size(emu, criterion, two):
             assert float((sd[k] - v).abs().max()) < 1e-9, k
         if "num_batches" in k:
             assert int(sd[k]) == int(v), k
+
+
+def test_second_backward_accumulates_on_the_flat_gradient_path(emu):
+    """torch.autograd semantics the reference's loop relies on: without zero_grad(set_to_none=True) a second backward
+    ADDS to .grad.  The engine writes gradients straight into the flat buffer views, so it must notice that .grad
+    already is that view (gradient accumulation over micro-batches / zero_grad(set_to_none=False))."""
+    ts = build("focal", batch_size=2)
+    assert ts.flat is not None
+    img, labels, ldw, weather, cw = O.synthetic_batch(2, 128, 256, seed=3, two_crops=False, cell=32)
+    ts.model.eval()                                   # deterministic BatchNorm: both passes see the same function
+
+    def run():
+        seg, _, _, _ = ts.model(img)
+        loss = ts.criterion(seg, labels.clone(), dict(label_distance_weight=ldw))
+        loss.backward()
+
+    run()
+    params = [p for p in ts.model.parameters() if p.grad is not None]
+    assert params and all(p.grad.data_ptr() == ts.flat.grad_view[p].data_ptr() for p in params if p in ts.flat.grad_view)
+    once = [p.grad.detach().clone() for p in params]
+    run()                                             # no zero_grad in between
+    for p, g1 in zip(params, once):
+        assert torch.allclose(p.grad, 2 * g1, rtol=1e-5, atol=1e-9)
+    ts.model.zero_grad(set_to_none=False)             # grads zeroed in place, .grad still the flat view
+    run()
+    for p, g1 in zip(params, once):
+        assert torch.allclose(p.grad, g1, rtol=1e-5, atol=1e-9)
+    ts.model.zero_grad()                              # set_to_none=True: the fast path writes in place again
+    run()
+    for p, g1 in zip(params, once):
+        assert torch.equal(p.grad, g1) and p.grad.data_ptr() == ts.flat.grad_view[p].data_ptr()
