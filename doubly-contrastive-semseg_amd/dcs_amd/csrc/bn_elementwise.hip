@@ -17,7 +17,12 @@ __global__ __launch_bounds__(256)
 void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                            const float* __restrict__ masksrc, const float* __restrict__ bn,
                            float* __restrict__ partial, long long rows, int Ctot, int cstride, int groups, int relu) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][RL][C]
+  // Per-thread and per-block accumulation in DOUBLE: the BatchNorm-backward sums (sum g, sum g*xhat) cancel heavily
+  // (their terms have mixed signs) and a sequential fp32 chain over a thread's few hundred rows loses what the
+  // reference's CPU batch_norm_backward (double accumulators, at::acc_type<float, false>) keeps: measured 8-33x the
+  // reference's own fp32-vs-fp64 error on stem / layer1 BatchNorm gradients with fp32 chains.  The kernel is HBM-bound
+  // (two streamed tensors), the fp64 adds are free.  Partials are rounded to fp32 once per group.
+  extern __shared__ __attribute__((aligned(16))) double smd[];   // [2][RL][C]
   const int cbase = blockIdx.z * 512;
   const int C = Ctot - cbase < 512 ? Ctot - cbase : 512;
   const int C4 = C >> 2;
@@ -29,7 +34,7 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
   const long long rbeg = (long long)gi * rpg;
   const long long rend = rbeg + rpg < rows ? rbeg + rpg : rows;
   const float* xb = x + (long long)b * rows * cstride + cbase;
-  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
   if (rl < RL) {
     float4 sc, sh, mu, is;
     if (MODE == 1) {
@@ -41,9 +46,9 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
       const long long off = r * cstride + col4 * 4;
       float4 v = ld4(xb + off);
       if (MODE == 0) {
-        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-        s1.x = fmaf(v.x, v.x, s1.x); s1.y = fmaf(v.y, v.y, s1.y);
-        s1.z = fmaf(v.z, v.z, s1.z); s1.w = fmaf(v.w, v.w, s1.w);
+        const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] += d[e]; a1[e] = fma(d[e], d[e], a1[e]); }
       } else {
         const float4 yy = ld4(y + cbase + off);
         if (masksrc) {
@@ -54,20 +59,24 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
           v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
           v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
         }
-        s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-        s1.x = fmaf(v.x, (yy.x - mu.x) * is.x, s1.x); s1.y = fmaf(v.y, (yy.y - mu.y) * is.y, s1.y);
-        s1.z = fmaf(v.z, (yy.z - mu.z) * is.z, s1.z); s1.w = fmaf(v.w, (yy.w - mu.w) * is.w, s1.w);
+        const float xh[4] = {(yy.x - mu.x) * is.x, (yy.y - mu.y) * is.y, (yy.z - mu.z) * is.z, (yy.w - mu.w) * is.w};
+        const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { a0[e] += d[e]; a1[e] = fma(d[e], (double)xh[e], a1[e]); }
       }
     }
-    st4(&sm[(0 * RL + rl) * C + col4 * 4], s0);
-    st4(&sm[(1 * RL + rl) * C + col4 * 4], s1);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      smd[(0 * RL + rl) * C + col4 * 4 + e] = a0[e];
+      smd[(1 * RL + rl) * C + col4 * 4 + e] = a1[e];
+    }
   }
   __syncthreads();
   for (int t = tid; t < 2 * C; t += 256) {
     const int which = t / C, c = t - which * C;
-    float s = 0.f;
-    for (int k = 0; k < RL; ++k) s += sm[(which * RL + k) * C + c];
-    partial[(((long long)b * groups + gi) * 2 + which) * Ctot + cbase + c] = s;
+    double s = 0.0;
+    for (int k = 0; k < RL; ++k) s += smd[(which * RL + k) * C + c];
+    partial[(((long long)b * groups + gi) * 2 + which) * Ctot + cbase + c] = (float)s;
   }
 }
 
@@ -75,12 +84,38 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
 // groups gl, gl+32, ... in double (independent 16-B loads, unrolled), then the 32 lanes are added in fixed order.
 __global__ __launch_bounds__(256)
 void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int groups, int C,
-                                    float scale) {
+                                    float scale, double moments_count) {
   __shared__ double sm[32][8][4];
   const int b = blockIdx.y;
+  const long long ld = 2ll * C;
+  if (moments_count > 0.0) {
+    // out[0][c] = mean, out[1][c] = biased variance, formed in double from the double totals (E[x^2] - mean^2 cancels
+    // when |mean| >> std; rounding the two sums to fp32 first would lose those digits).  32 channels x 8 group lanes.
+    if (blockIdx.x * 32 >= C) return;
+    const int cl = threadIdx.x & 31, gl2 = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C) {
+      const float* p = partial + (long long)b * groups * ld;
+      for (int gi = gl2; gi < groups; gi += 8) { s0 += (double)p[(long long)gi * ld + c]; s1 += (double)p[(long long)gi * ld + C + c]; }
+    }
+    double (*sm2)[32][2] = reinterpret_cast<double (*)[32][2]>(&sm[0][0][0]);
+    sm2[gl2][cl][0] = s0; sm2[gl2][cl][1] = s1;
+    __syncthreads();
+    if (threadIdx.x < 32 && c < C) {
+      double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { t0 += sm2[k][cl][0]; t1 += sm2[k][cl][1]; }
+      const double m = t0 / moments_count;
+      double var = t1 / moments_count - m * m;
+      if (var < 0.0) var = 0.0;
+      out[(long long)b * ld + c] = (float)m;
+      out[(long long)b * ld + C + c] = (float)var;
+    }
+    return;
+  }
   const int cl = threadIdx.x & 7, gl = threadIdx.x >> 3;
   const int col = (blockIdx.x * 8 + cl) * 4;
-  const long long ld = 2ll * C;
   double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
   if (col < 2 * C) {
     const float* p = partial + (long long)b * groups * ld + col;
@@ -112,8 +147,9 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, const float* 
   if (c >= C) return;
   float mean, invstd;
   if (training) {
-    const double m = (double)sums[c] / count;
-    double var = (double)sums[C + c] / count - m * m;
+    // training == 2: sums already holds (mean, biased variance) formed in double by dcs_colsum_final
+    const double m = training == 2 ? (double)sums[c] : (double)sums[c] / count;
+    double var = training == 2 ? (double)sums[C + c] : (double)sums[C + c] / count - m * m;
     if (var < 0.0) var = 0.0;
     mean = (float)m;
     invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -323,7 +359,7 @@ extern "C" int dcs_colsum_partial(const float* x, const float* y, const float* m
   DCS_CHECK_ARG(mode == 0 || (mode == 1 && y && bn && cstride == C));
   const int Cb = C < 512 ? C : 512;
   const int C4 = Cb / 4, RL = 256 / C4;
-  const size_t sh = (size_t)2 * RL * Cb * sizeof(float);
+  const size_t sh = (size_t)2 * RL * Cb * sizeof(double);
   dim3 grid((unsigned)groups, (unsigned)B, (unsigned)((C + 511) / 512));
   if (mode == 0)
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), sh, dcs_stream(stream), x, y, masksrc, bn, partial,
@@ -334,10 +370,12 @@ extern "C" int dcs_colsum_partial(const float* x, const float* y, const float* m
   DCS_LAUNCH_RET();
 }
 
-extern "C" int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale, void* stream) {
+extern "C" int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale,
+                                double moments_count, void* stream) {
   DCS_CHECK_ARG(partial && out && B > 0 && groups > 0 && C > 0 && (C & 1) == 0 && dcs_aligned16(partial));
+  DCS_CHECK_ARG(moments_count == 0.0 || (moments_count > 0.0 && scale == 1.f));
   hipLaunchKernelGGL(colsum_final_kernel, dim3((unsigned)((2 * C + 31) / 32), (unsigned)B), dim3(256), 0, dcs_stream(stream),
-                     partial, out, groups, C, scale);
+                     partial, out, groups, C, scale, moments_count);
   DCS_LAUNCH_RET();
 }
 

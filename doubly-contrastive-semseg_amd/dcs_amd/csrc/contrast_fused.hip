@@ -1,0 +1,928 @@
+// Fused embedding-similarity / InfoNCE loss: S = X X^T is NEVER written to memory.
+//
+// Replaces the chain behind utils/loss.py:339-389 (PixelContrastLoss._contrastive, mode 0) and utils/loss.py:175-204
+// (SupConLoss, mode 1) of the reference: matmul -> max -> subtract -> F.normalize -> masked exp / log reductions ->
+// mean, and its autograd backward.  For anchors X [A,C] with float labels y [A] (y < 0 marks a padding row of the
+// fixed-shape data-parallel all-gather: it takes part in nothing) the kernels produce
+//     loss = (1/A_v) sum_i loss_i          and          dX = (G + G^T) X,   G_ij = d loss / d S_ij,
+// where, for a valid row i over the valid columns j (it = 1/T):
+//     m_i = max_j S_ij it,  u_ij = S_ij it - m_i,  L_ij = u_ij / max(||u_i||_2, 1e-12),  E_ij = exp(L_ij)
+//     mode 0:  den_i = sum_{y_j != y_i} E_ij                loss_i = -1/cnt_i sum_{p in pos(i)} (L_ip - log(E_ip + den_i))
+//     mode 1:  den_i = sum_{j != i} E_ij                    loss_i = -1/cnt_i sum_j w_ij (L_ij - log den_i)
+//     pos(i) = {j != i : y_j == y_i},  w_ij = [j in pos(i)]  (or an explicit [b,b] mask tiled over the views, mode 1).
+//
+// Two kernel families, picked by A:
+//   * A <= DCS_CONTRAST_SMALL_MAX (the per-rank anchor set, <= 608 rows at C3): TWO launches.
+//       stats: one block per 16-row strip keeps its S strip [16][A] in LDS (MFMA 16x16x4, every wave a different
+//              column tile), so the four dependent row sweeps (max; norm; denominators; positives) read LDS.
+//       final: one block per 16-row strip recomputes its S tiles, forms G_ij + G_ji in registers from the row
+//              records of BOTH rows (S is symmetric, so G_ji needs no second GEMM), and accumulates
+//              dX_I += Gsym(I,J) X_J on the matrix cores; block 0 also reduces the loss.
+//   * larger A (the all-gathered global set of the data-parallel step, 4864 rows at C4): see the tile kernels below --
+//       three SYMMETRIC statistics sweeps over the upper-triangular 64x64 tiles (each tile feeds the statistics of its
+//       rows AND, transposed, of its columns: half the similarity FLOPs per sweep), then the final sweep.
+// Mode 1 with A <= small max accumulates S in float64 on the f64 matrix cores (v_mfma_f64_16x16x4_f64): pooled image
+// embeddings of one batch are nearly parallel, S_ij it - m_i then cancels 4-5 digits, and a k-ordered fp32 FMA chain
+// (what the f32 MFMA is) loses them where the reference's blocked CPU GEMM does not (measured: 7x the reference's own
+// fp32-vs-fp64 error on the projection-head gradients; with f64 accumulation 0.1x).  2B <= 512 rows: free.
+#include "dcs_common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int REC = 8;   // floats per row record: m (float, or double in slots 0-1), [2] rn, [3] den, [4] 1/cnt, [5] qv, [6] dot, [7] clamp
+
+template <typename ACC> struct Mfma16;
+template <> struct Mfma16<float> {
+  typedef f32x4 acc_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0.f, 0.f, 0.f, 0.f}; }
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }      // C/D: col = lane&15
+};
+template <> struct Mfma16<double> {
+  typedef f64x4 acc_t;
+  static __device__ __forceinline__ acc_t zero() { return acc_t{0.0, 0.0, 0.0, 0.0}; }
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64((double)a, (double)b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }      // f64 C/D map differs
+};
+
+__device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
+
+// One 16x16 tile of S = X_I X_J^T.  Lane (r = lane&15, q = lane>>4) holds, per 16-channel step s, the float4
+// X[row r][16 s + 4 q .. +3] of BOTH operands; component c of step s is k = 16 s + 4 q + c on both sides, so every MFMA
+// (4 k values: q = 0..3) multiplies matching channels whatever the order (any k permutation is legal when A and B agree).
+// xa: the strip's rows (kept in registers when C <= 128), rowJ: this lane's row of the column tile (or -1).
+template <typename ACC, int NS>
+__device__ __forceinline__ typename Mfma16<ACC>::acc_t s_tile(const float4 (&xa)[NS], const float* __restrict__ X, const int ldx,
+                                                             const int C, const int rowI, const int rowJ, const int q) {
+  typename Mfma16<ACC>::acc_t acc = Mfma16<ACC>::zero();
+  const int nchunk = (C + 16 * NS - 1) / (16 * NS);
+  for (int ch = 0; ch < nchunk; ++ch) {
+    float4 xb[NS], xs[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      const int k = (ch * NS + s) * 16 + 4 * q;
+      xb[s] = (rowJ >= 0 && k < C) ? ldg4(X + (long long)rowJ * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (nchunk > 1) xs[s] = (rowI >= 0 && k < C) ? ldg4(X + (long long)rowI * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else xs[s] = xa[s];
+    }
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc = Mfma16<ACC>::mma(comp(xs[s], c), comp(xb[s], c), acc);
+  }
+  return acc;
+}
+
+template <int W>
+__device__ __forceinline__ float grp_sum(float v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+template <int W, typename T>
+__device__ __forceinline__ T grp_max(T v) {
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) { const T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+
+template <typename ACC> __device__ __forceinline__ void rec_put_m(float* r, ACC m);
+template <> __device__ __forceinline__ void rec_put_m<float>(float* r, float m) { r[0] = m; r[1] = 0.f; }
+template <> __device__ __forceinline__ void rec_put_m<double>(float* r, double m) { *reinterpret_cast<double*>(r) = m; }
+template <typename ACC> __device__ __forceinline__ ACC rec_get_m(const float* r);
+template <> __device__ __forceinline__ float rec_get_m<float>(const float* r) { return r[0]; }
+template <> __device__ __forceinline__ double rec_get_m<double>(const float* r) { return *reinterpret_cast<const double*>(r); }
+
+// weight of column j as a positive of row i (self excluded by the caller)
+__device__ __forceinline__ float pos_weight(const float* __restrict__ mask, const int mb, const int i, const int j,
+                                            const float yi, const float yj) {
+  return mask ? mask[(i % mb) * mb + (j % mb)] : (yi == yj ? 1.f : 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// small-A statistics: block = one 16-row strip, S strip resident in LDS.
+template <typename ACC, int NW>
+__global__ __launch_bounds__(NW * 64)
+void contrast_small_stats_kernel(const float* __restrict__ X, const int ldx, const float* __restrict__ y, const int ldy,
+                                 const float* __restrict__ mask, const int mb, const int A, const int C, const int mode,
+                                 const float it, float* __restrict__ rec, float* __restrict__ loss_row, const int AP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  ACC* Ss = reinterpret_cast<ACC*>(smem_raw);                       // [16][AP]
+  float* ys = reinterpret_cast<float*>(Ss + 16 * AP);               // [AP]
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int i0 = blockIdx.x * 16;
+  for (int j = tid; j < AP; j += NW * 64) ys[j] = j < A ? y[(long long)j * ldy] : -1.f;
+  const int rowI = i0 + li < A ? i0 + li : -1;
+  float4 xa[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = 16 * s + 4 * q;
+    xa[s] = (rowI >= 0 && k < C) ? ldg4(X + (long long)rowI * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int ntile = (A + 15) >> 4;
+  for (int jt = wid; jt < ntile; jt += NW) {
+    const int rowJ = 16 * jt + li < A ? 16 * jt + li : -1;
+    const typename Mfma16<ACC>::acc_t acc = s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Ss[Mfma16<ACC>::row(lane, r) * AP + 16 * jt + li] = acc[r];
+  }
+  __syncthreads();
+
+  constexpr int TPR = NW * 4;                                       // threads per row (a lane group inside one wave)
+  const int ri = tid / TPR, rl = tid % TPR;
+  const int i = i0 + ri;
+  const bool live = i < A && ys[i < AP ? i : 0] >= 0.f;
+  const float yi = live ? ys[i] : -2.f;
+  const ACC* srow = Ss + ri * AP;
+  const ACC itA = (ACC)it;
+  // sweep 1: row max of S/T over the valid columns (utils/loss.py:363, :179)
+  ACC m = (ACC)(-3.0e38f);
+  for (int j = rl; j < A; j += TPR)
+    if (ys[j] >= 0.f) { const ACC v = srow[j] * itA; m = v > m ? v : m; }
+  m = grp_max<TPR, ACC>(m);
+  // sweep 2: ||u_i||_2, F.normalize eps 1e-12 (:366, :194)
+  float n2 = 0.f;
+  for (int j = rl; j < A; j += TPR)
+    if (ys[j] >= 0.f) { const float u = (float)(srow[j] * itA - m); n2 = fmaf(u, u, n2); }
+  n2 = grp_sum<TPR>(n2);
+  const float nraw = sqrtf(n2);
+  const float rn = 1.f / fmaxf(nraw, 1e-12f);
+  // sweep 3: denominators, positive counts, and the E.L sums the gradient's <dL, L> needs
+  float den = 0.f, cnt = 0.f, sEL = 0.f, swL = 0.f;
+  for (int j = rl; j < A; j += TPR) {
+    const float yj = ys[j];
+    if (yj < 0.f) continue;
+    const float L = (float)(srow[j] * itA - m) * rn;
+    const float E = expf(L);
+    if (mode == 0) {
+      if (yj != yi) { den += E; sEL = fmaf(E, L, sEL); }               // neg_logits (:376-377)
+      else if (j != i) cnt += 1.f;
+    } else {
+      if (j != i) {                                                    // exp_logits * logits_mask (:196)
+        den += E; sEL = fmaf(E, L, sEL);
+        const float w = pos_weight(mask, mb, i, j, yi, yj);
+        cnt += w; swL = fmaf(w, L, swL);
+      }
+    }
+  }
+  den = grp_sum<TPR>(den); cnt = grp_sum<TPR>(cnt); sEL = grp_sum<TPR>(sEL); swL = grp_sum<TPR>(swL);
+  float lp, qv = 0.f, dot;
+  const float icnt = 1.f / cnt;                                        // cnt == 0 -> inf -> NaN loss like the reference
+  if (mode == 0) {
+    // sweep 4 (positives only): log-probabilities and q = sum_pos 1/(E + den)
+    float slp = 0.f, sq = 0.f, sdl = 0.f;
+    for (int j = rl; j < A; j += TPR) {
+      if (j == i || ys[j] != yi) continue;
+      const float L = (float)(srow[j] * itA - m) * rn;
+      const float d = expf(L) + den;
+      const float id = 1.f / d;
+      slp += L - logf(d); sq += id; sdl = fmaf(den * id, L, sdl);
+    }
+    lp = grp_sum<TPR>(slp); qv = grp_sum<TPR>(sq); sdl = grp_sum<TPR>(sdl);
+    dot = (qv * sEL - sdl) * icnt;
+  } else {
+    lp = swL - cnt * logf(den);
+    dot = sEL / den - swL * icnt;
+  }
+  if (rl == 0 && i < A) {
+    float* r = rec + (long long)i * REC;
+    if (live) {
+      rec_put_m<ACC>(r, m);
+      r[2] = rn; r[3] = den; r[4] = icnt; r[5] = qv; r[6] = dot; r[7] = nraw <= 1e-12f ? 1.f : 0.f;
+      loss_row[i] = -lp * icnt;                                        // temperature / base_temperature = 1
+    } else {
+#pragma unroll
+      for (int e = 0; e < REC; ++e) r[e] = 0.f;
+      loss_row[i] = 0.f;
+    }
+  }
+}
+
+// d loss / d S_ab (before the 1/A_v mean) from the record of row a; same = (y_a == y_b), self = (a == b), w = positive
+// weight of b for a.  ACC-precision shift like the statistics sweeps.
+template <typename ACC>
+__device__ __forceinline__ float g_entry(const ACC s, const float* __restrict__ ra, const ACC itA, const float it,
+                                         const int mode, const bool same, const bool self, const float w) {
+  const float rn = ra[2], den = ra[3], icnt = ra[4], qv = ra[5], dot = ra[6];
+  const float L = (float)(s * itA - rec_get_m<ACC>(ra)) * rn;
+  const float E = expf(L);
+  float dL;
+  if (mode == 0) dL = same ? (self ? 0.f : -(den / (E + den)) * icnt) : E * qv * icnt;
+  else dL = self ? 0.f : (E / den - w * icnt);
+  const float du = ra[7] != 0.f ? dL : dL - L * dot;                  // through F.normalize (clamped norm: no projection)
+  return du * rn * it;
+}
+
+// small-A final sweep: dX_I = sum_J (G + G^T)(I,J) X_J, one block per 16-row strip, waves split the column tiles.
+// gsym_out != null (C > 128: the feature width of DeepLab's pixel contrast): G + G^T is written out [A][ldg] instead
+// and the caller finishes dX with one GEMM.
+template <typename ACC, int NW>
+__global__ __launch_bounds__(NW * 64)
+void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, const float* __restrict__ y, const int ldy,
+                                 const float* __restrict__ mask, const int mb, const int A, const int C, const int mode,
+                                 const float it, const float* __restrict__ rec, const float* __restrict__ loss_row,
+                                 float* __restrict__ loss, float* __restrict__ dX, const int lddx,
+                                 float* __restrict__ gsym_out, const int ldg) {
+  constexpr int XLD = 144;                       // 128 + 16: rows 16 banks apart -> conflict-free k-strided B reads
+  constexpr int GLD = 17;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* sm = reinterpret_cast<float*>(smem_raw);
+  float* recI = sm;                              // [16][REC]
+  float* yI = recI + 16 * REC;                   // [16]
+  float* red = yI + 16;                          // [NW] block reduction scratch
+  float* Gt = red + NW + (4 - (NW & 3)) % 4;     // per wave [16][GLD]
+  float* Xt = Gt + NW * 16 * GLD + (4 - ((NW * 16 * GLD) & 3)) % 4;   // per wave [16][XLD]; later the cross-wave reduce buffer
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, q = lane >> 4;
+  const int i0 = blockIdx.x * 16;
+  // number of valid rows (the mean's denominator): every block counts the labels itself (A floats from L2)
+  float nv = 0.f;
+  for (int j = tid; j < A; j += NW * 64) nv += y[(long long)j * ldy] >= 0.f ? 1.f : 0.f;
+  nv = dcs_wave_sum(nv);
+  if (lane == 0) red[wid] = nv;
+  if (tid < 16 * REC) recI[tid] = (i0 + tid / REC < A) ? rec[(long long)i0 * REC + tid] : 0.f;
+  if (tid < 16) yI[tid] = i0 + tid < A ? y[(long long)(i0 + tid) * ldy] : -1.f;
+  __syncthreads();
+  float av = 0.f;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) av += red[w];
+  const float inv_av = 1.f / av;
+  const int rowI = i0 + li < A ? i0 + li : -1;
+  float4 xa[8];
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = 16 * s + 4 * q;
+    xa[s] = (rowI >= 0 && k < C) ? ldg4(X + (long long)rowI * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f32x4 dacc[8];
+#pragma unroll
+  for (int ct = 0; ct < 8; ++ct) dacc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float* gt = Gt + wid * 16 * GLD;
+  float* xt = Xt + wid * 16 * XLD;
+  const ACC itA = (ACC)it;
+  const int ntile = (A + 15) >> 4;
+  for (int jt = wid; jt < ntile; jt += NW) {
+    const int j = 16 * jt + li;
+    const int rowJ = j < A ? j : -1;
+    const typename Mfma16<ACC>::acc_t acc = s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
+    float rj[REC];
+    const float yj = rowJ >= 0 ? y[(long long)j * ldy] : -1.f;
+    {
+      const float4 a = rowJ >= 0 ? ldg4(rec + (long long)j * REC) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b = rowJ >= 0 ? ldg4(rec + (long long)j * REC + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rj[0] = a.x; rj[1] = a.y; rj[2] = a.z; rj[3] = a.w; rj[4] = b.x; rj[5] = b.y; rj[6] = b.z; rj[7] = b.w;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int il = Mfma16<ACC>::row(lane, r);
+      const int i = i0 + il;
+      const float yi = yI[il];
+      float gs = 0.f;
+      if (yi >= 0.f && yj >= 0.f) {
+        const bool same = yi == yj, self = i == j;
+        const float wij = (mode == 1 && !self) ? pos_weight(mask, mb, i, j, yi, yj) : 0.f;
+        const float wji = (mode == 1 && !self) ? pos_weight(mask, mb, j, i, yj, yi) : 0.f;
+        gs = (g_entry<ACC>(acc[r], recI + il * REC, itA, it, mode, same, self, wij) +
+              g_entry<ACC>(acc[r], rj, itA, it, mode, same, self, wji)) * inv_av;
+      }
+      if (gsym_out) { if (i < A && j < A) gsym_out[(long long)i * ldg + j] = gs; }
+      else gt[il * GLD + li] = gs;
+    }
+    if (gsym_out) continue;
+    // X_J tile -> per-wave LDS image [16 j][XLD] (the k-strided B operand of the second product)
+    {
+      const int nchunk = 1;                                            // C <= 128 on this path
+      (void)nchunk;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int k = 16 * s + 4 * q;
+        const float4 v = (rowJ >= 0 && k < C) ? ldg4(X + (long long)rowJ * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(&xt[li * XLD + k]) = v;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // dX_I[16][C] += Gsym[16 i][16 j] X_J[16 j][C]: A operand Gt[i = li][j = 4 kk + q], B operand xt[j = 4 kk + q][c = 16 ct + li]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const float a = gt[li * GLD + 4 * kk + q];
+#pragma unroll
+      for (int ct = 0; ct < 8; ++ct) {
+        const float b = xt[(4 * kk + q) * XLD + 16 * ct + li];
+        dacc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, dacc[ct], 0, 0, 0);
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (!gsym_out) {
+    // cross-wave reduction in fixed order: red2[w][16][XLD] aliases the X tiles (all waves are past their last read)
+    __syncthreads();
+    float* red2 = Xt;
+#pragma unroll
+    for (int ct = 0; ct < 8; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red2[(wid * 16 + 4 * q + r) * XLD + 16 * ct + li] = dacc[ct][r];
+    __syncthreads();
+    for (int e = tid; e < 16 * 32; e += NW * 64) {                     // 16 rows x 32 float4
+      const int il = e >> 5, c4 = (e & 31) * 4;
+      if (i0 + il >= A || c4 >= C) continue;
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        const float4 v = *reinterpret_cast<const float4*>(&red2[(w * 16 + il) * XLD + c4]);
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(&dX[(long long)(i0 + il) * lddx + c4]) = s;
+    }
+  }
+  if (blockIdx.x == 0) {
+    // loss = (1/A_v) sum_i loss_i, fixed-order tree (deterministic)
+    __syncthreads();
+    float s = 0.f;
+    for (int j = tid; j < A; j += NW * 64) s += loss_row[j];
+    s = dcs_wave_sum(s);
+    if (lane == 0) red[wid] = s;
+    __syncthreads();
+    if (tid == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) t += red[w];
+      loss[0] = t * inv_av;
+    }
+  }
+}
+
+// ==================================================================================================================
+// Large-A family (the all-gathered global anchor set of the data-parallel step: 8 x 608 = 4864 rows at C4).
+//
+// One kernel skeleton, contrast_strip_kernel<PHASE>: a block owns a 64-row strip I (its A operand lives in registers)
+// and walks a chunk of 64-column tiles J; per tile the 4 waves compute S(I,J) = X_I X_J^T with v_mfma_f32_32x32x2
+// (X_J staged once per tile in LDS, register-staged prefetch of the next tile) and hand the accumulators to the phase:
+//   PHASE 1-3 = row statistics, SYMMETRIC: only tiles J >= I are visited; element (i,j) feeds the statistics of row i
+//     (row direction: per-lane accumulators over the whole chunk, ONE cross-lane register-transpose reduction per
+//     chunk) and, because S_ji = S_ij, of row j (column direction: 16 in-lane adds + one shuffle per tile).  Half the
+//     similarity FLOPs of a row-only sweep.  Partials go to P[slot][row][4]; a combine kernel sums a row's slots in
+//     fixed order (deterministic, no float atomics) and derives the row record for the next phase:
+//       1: max, sum (s - r), sum (s - r)^2 with the reference shift r_i = S_ii/T   -> m_i, ||u_i||
+//       2: den, cnt, sum E L, sum w L                                              -> den_i, 1/cnt_i (mode 1: done)
+//       3: (mode 0, positives only) sum log-prob, q = sum 1/(E+den), sum den L/(E+den)   -> loss_i, q_i, <dL, L>_i
+//   PHASE 4 = final sweep over ALL tiles J (chunked for parallelism): Gsym(I,J) = G_ij + G_ji in registers from the
+//     records of both rows, staged through LDS as the A operand of dX_I += Gsym(I,J) X_J (second MFMA product, X_J
+//     already in LDS); chunk partials of dX go to slabs that dcs_reduce_slab-style code sums in fixed order.
+// FLOPs: 3 x 0.5 + 2 units of A^2 C 2 (one unit = 6.06 GFLOP at A = 4864, C = 128) against 3 algorithmic units.
+constexpr int TB = 64;                 // tile edge
+constexpr int XLDL = 132;              // LDS row stride of the X_J tile: 128 + 4 (odd number of 16-B slots: conflict-free b128 reads)
+constexpr int GLDL = 68;               // LDS row stride of the Gsym tile
+
+struct StripParams {
+  const float* X; int ldx; const float* y; int ldy; const float* mask; int mb;
+  int A, C, mode, ntile, CH;           // CH = tiles per chunk
+  float it;
+  const float* rnorm;                  // [A] reference shift r_i = it * ||x_i||^2
+  const float* rec;                    // [A][REC] row records (phases >= 2)
+  float* P;                            // [ntile][A][4] partials (phases 1-3)
+  float* slab;                         // [nchunk][A][C] dX partials (phase 4)
+  float* gsym; int ldg;                // phase 4 with C > 128: Gsym written out instead
+  const float* av;                     // [1] number of valid rows
+};
+
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+__device__ __forceinline__ int row32(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Sum (or max) of v[0..16) over the 32 lanes that share lane>>5.  Register-transpose reduction: 16 shuffles instead of
+// 80.  Returns in every lane the total of register index (lane & 31) >> 1.
+template <bool MAX>
+__device__ __forceinline__ float xlane32(const float (&v)[16], const int l31) {
+  auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+  float w8[8], w4[4], w2[2];
+  const bool b4 = l31 & 16, b3 = l31 & 8, b2 = l31 & 4, b1 = l31 & 2;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { const float send = b4 ? v[k] : v[k + 8], keep = b4 ? v[k + 8] : v[k]; w8[k] = op(keep, __shfl_xor(send, 16, 64)); }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { const float send = b3 ? w8[k] : w8[k + 4], keep = b3 ? w8[k + 4] : w8[k]; w4[k] = op(keep, __shfl_xor(send, 8, 64)); }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { const float send = b2 ? w4[k] : w4[k + 2], keep = b2 ? w4[k + 2] : w4[k]; w2[k] = op(keep, __shfl_xor(send, 4, 64)); }
+  const float send = b1 ? w2[0] : w2[1], keep = b1 ? w2[1] : w2[0];
+  const float x = op(keep, __shfl_xor(send, 2, 64));
+  return op(x, __shfl_xor(x, 1, 64));
+}
+
+template <int PHASE, int MODE>
+__global__ __launch_bounds__(256, 2)
+void contrast_strip_kernel(const StripParams p) {
+  constexpr bool STATS = PHASE <= 3;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  float* XJ = reinterpret_cast<float*>(smem_raw);                 // [64][XLDL]
+  float* recI = XJ + TB * XLDL;                                   // [64][REC]   (+ yI, rI in slots of their own)
+  float* recJ = recI + TB * REC;                                  // [64][REC]
+  float* auxI = recJ + TB * REC;                                  // [64][2] = y_i, r_i
+  float* auxJ = auxI + TB * 2;                                    // [64][2]
+  float* red = auxJ + TB * 2;                                     // [2][64][4] cross-wave reduction scratch
+  float* Gs = red + 2 * TB * 4;                                   // [64][GLDL]  (phase 4)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int A = p.A, C = p.C;
+  constexpr int mode = MODE;
+  const float it = p.it;
+
+  // block -> (strip I, first tile jbeg, end tile jend)
+  int I, jbeg, jend;
+  {
+    int id = blockIdx.x;
+    if (STATS) {
+      I = 0;
+      for (;;) { const int n = (p.ntile - I + p.CH - 1) / p.CH; if (id < n) break; id -= n; ++I; }
+      jbeg = I + id * p.CH;
+    } else {
+      const int n = (p.ntile + p.CH - 1) / p.CH;
+      I = id / n;
+      jbeg = (id - I * n) * p.CH;
+    }
+    jend = jbeg + p.CH < p.ntile ? jbeg + p.CH : p.ntile;
+  }
+  const int i0 = I * TB;
+  const float inv_av = PHASE == 4 ? 1.f / p.av[0] : 0.f;
+
+  // strip-resident row data
+  for (int e = tid; e < TB * REC; e += 256) {
+    const int r = i0 + e / REC;
+    recI[e] = (PHASE >= 2 && r < A) ? p.rec[(long long)i0 * REC + e] : 0.f;
+  }
+  if (tid < TB) {
+    const int r = i0 + tid;
+    auxI[2 * tid] = r < A ? p.y[(long long)r * p.ldy] : -1.f;
+    auxI[2 * tid + 1] = r < A ? p.rnorm[r] : 0.f;
+  }
+  // A operand: lane (r = l31, h) holds X_I[32 wm + l31][8 g + 4 h .. +3] for the 16 k8-groups of a 128-channel chunk
+  const int rowA = i0 + 32 * wm + l31 < A ? i0 + 32 * wm + l31 : -1;
+  const int nkc = (C + 127) >> 7;
+  float4 af[16];
+  auto load_a = [&](int kc) {
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const int k = kc * 128 + 8 * g + 4 * h;
+      af[g] = (rowA >= 0 && k < C) ? ldg4(p.X + (long long)rowA * p.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  if (nkc == 1) load_a(0);
+  // X_J staging: thread -> 8 float4 of the [64][128] chunk image
+  float4 st[8];
+  auto load_j = [&](int J, int kc) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 256 * q, r = e >> 5, k = kc * 128 + (e & 31) * 4;
+      const int row = J * TB + r;
+      st[q] = (J < jend && row < A && k < C) ? ldg4(p.X + (long long)row * p.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_j = [&]() {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int e = tid + 256 * q, r = e >> 5, k4 = (e & 31) * 4;
+      *reinterpret_cast<float4*>(&XJ[r * XLDL + k4]) = st[q];
+    }
+  };
+
+  // phase accumulators
+  constexpr bool HAS3 = PHASE == 2 && MODE == 1;
+  float ra0[16], ra1[16], ra2[16], ra3[HAS3 ? 16 : 1];           // row direction (stats phases), per-lane partials
+  f32x16 dacc[2];                                                // phase 4: dX strip, wave = rows 32 wm.., cols 64 wn + 32 b
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { ra0[r] = PHASE == 1 ? -3.0e38f : 0.f; ra1[r] = 0.f; ra2[r] = 0.f; if (HAS3) ra3[r] = 0.f; }
+#pragma unroll
+  for (int b = 0; b < 2; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dacc[b][r] = 0.f;
+
+  for (int J = jbeg; J < jend; ++J) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int kc = 0; kc < nkc; ++kc) {
+      load_j(J, kc);                                               // L2 latency is covered by the CU's other block
+      __syncthreads();                                             // readers of the previous XJ image are done
+      store_j();
+      if (kc == 0) {
+        for (int e = tid; e < TB * REC; e += 256) {
+          const int r = J * TB + e / REC;
+          recJ[e] = (PHASE >= 2 && r < A) ? p.rec[(long long)J * TB * REC + e] : 0.f;
+        }
+        if (tid < TB) {
+          const int r = J * TB + tid;
+          auxJ[2 * tid] = r < A ? p.y[(long long)r * p.ldy] : -1.f;
+          auxJ[2 * tid + 1] = r < A ? p.rnorm[r] : 0.f;
+        }
+      }
+      if (nkc > 1) load_a(kc);
+      __syncthreads();
+      const float* bj = &XJ[(32 * wn + l31) * XLDL + 4 * h];
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(bj + 8 * g);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, b.w, acc, 0, 0, 0);
+      }
+    }
+    // ---- epilogue: lane holds S[i = 32 wm + row32(r, h)][j = 32 wn + l31], r = 0..15 ----
+    const int jl = 32 * wn + l31, jg = J * TB + jl;
+    const float yj = auxJ[2 * jl], rj = auxJ[2 * jl + 1];
+    const bool diag = J == I;
+    if (PHASE == 1) {
+      float c0 = -3.0e38f, c1 = 0.f, c2 = 0.f;                     // column direction: statistics of row j over the rows i
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il = 32 * wm + row32(r, h);
+        const float yi = auxI[2 * il], ri = auxI[2 * il + 1];
+        const float v = acc[r] * it;
+        if (yi >= 0.f && yj >= 0.f) {
+          const float d = v - ri;
+          ra0[r] = fmaxf(ra0[r], v); ra1[r] += d; ra2[r] = fmaf(d, d, ra2[r]);
+          if (!diag) { const float e = v - rj; c0 = fmaxf(c0, v); c1 += e; c2 = fmaf(e, e, c2); }
+        }
+      }
+      if (!diag) {                                                 // uniform per block
+        c0 = fmaxf(c0, __shfl_xor(c0, 32, 64)); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+        if (h == 0) { float* q = &red[(wm * TB + jl) * 4]; q[0] = c0; q[1] = c1; q[2] = c2; q[3] = 0.f; }
+        __syncthreads();
+        if (tid < TB && J * TB + tid < A) {
+          const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
+          float* o = p.P + ((long long)I * A + J * TB + tid) * 4;
+          o[0] = fmaxf(q0[0], q1[0]); o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = 0.f;
+        }
+      }
+    } else if (PHASE == 2) {
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
+      const float mj = recJ[jl * REC], rnj = recJ[jl * REC + 2];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il = 32 * wm + row32(r, h), ig = i0 + il;
+        const float yi = auxI[2 * il];
+        if (yi < 0.f || yj < 0.f) continue;
+        const float v = acc[r] * it;
+        const bool same = yi == yj, self = ig == jg;
+        {                                                          // row i, column j
+          const float L = (v - recI[il * REC]) * recI[il * REC + 2];
+          const float E = expf(L);
+          if (mode == 0) { if (!same) { ra0[r] += E; ra2[r] = fmaf(E, L, ra2[r]); } else if (!self) ra1[r] += 1.f; }
+          else if (!self) {
+            const float w = pos_weight(p.mask, p.mb, ig, jg, yi, yj);
+            ra0[r] += E; ra2[r] = fmaf(E, L, ra2[r]); ra1[r] += w; if (HAS3) ra3[r] = fmaf(w, L, ra3[r]);
+          }
+        }
+        if (!diag) {                                               // row j, column i (S_ji = S_ij)
+          const float L = (v - mj) * rnj;
+          const float E = expf(L);
+          if (mode == 0) { if (!same) { c0 += E; c2 = fmaf(E, L, c2); } else c1 += 1.f; }
+          else {
+            const float w = pos_weight(p.mask, p.mb, jg, ig, yj, yi);
+            c0 += E; c2 = fmaf(E, L, c2); c1 += w; c3 = fmaf(w, L, c3);
+          }
+        }
+      }
+      if (!diag) {
+        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64); c3 += __shfl_xor(c3, 32, 64);
+        if (h == 0) { float* q = &red[(wm * TB + jl) * 4]; q[0] = c0; q[1] = c1; q[2] = c2; q[3] = c3; }
+        __syncthreads();
+        if (tid < TB && J * TB + tid < A) {
+          const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
+          float* o = p.P + ((long long)I * A + J * TB + tid) * 4;
+          o[0] = q0[0] + q1[0]; o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = q0[3] + q1[3];
+        }
+      }
+    } else if (PHASE == 3) {
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f;
+      const float mj = recJ[jl * REC], rnj = recJ[jl * REC + 2], denj = recJ[jl * REC + 3];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il = 32 * wm + row32(r, h), ig = i0 + il;
+        const float yi = auxI[2 * il];
+        if (yi < 0.f || yi != yj || ig == jg) continue;            // positives only
+        const float v = acc[r] * it;
+        {
+          const float den = recI[il * REC + 3];
+          const float L = (v - recI[il * REC]) * recI[il * REC + 2];
+          const float d = expf(L) + den, id = 1.f / d;
+          ra0[r] += L - logf(d); ra1[r] += id; ra2[r] = fmaf(den * id, L, ra2[r]);
+        }
+        if (!diag) {
+          const float L = (v - mj) * rnj;
+          const float d = expf(L) + denj, id = 1.f / d;
+          c0 += L - logf(d); c1 += id; c2 = fmaf(denj * id, L, c2);
+        }
+      }
+      if (!diag) {
+        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
+        if (h == 0) { float* q = &red[(wm * TB + jl) * 4]; q[0] = c0; q[1] = c1; q[2] = c2; q[3] = 0.f; }
+        __syncthreads();
+        if (tid < TB && J * TB + tid < A) {
+          const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
+          float* o = p.P + ((long long)I * A + J * TB + tid) * 4;
+          o[0] = q0[0] + q1[0]; o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = 0.f;
+        }
+      }
+    } else {
+      // PHASE 4: Gsym tile -> LDS (A operand of the second product) or -> global (wide features)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int il = 32 * wm + row32(r, h), ig = i0 + il;
+        const float yi = auxI[2 * il];
+        float gs = 0.f;
+        if (yi >= 0.f && yj >= 0.f) {
+          const bool same = yi == yj, self = ig == jg;
+          const float wij = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, ig, jg, yi, yj) : 0.f;
+          const float wji = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, jg, ig, yj, yi) : 0.f;
+          gs = (g_entry<float>(acc[r], recI + il * REC, it, it, mode, same, self, wij) +
+                g_entry<float>(acc[r], recJ + jl * REC, it, it, mode, same, self, wji)) * inv_av;
+        }
+        if (p.gsym) { if (ig < A && jg < A) p.gsym[(long long)ig * p.ldg + jg] = gs; }
+        else Gs[il * GLDL + jl] = gs;
+      }
+      if (!p.gsym) {
+        __syncthreads();
+        // dX[32 wm + ..][64 wn + 32 b + ..] += sum_j Gs[i][j] XJ[j][c]:  A lane (i = l31, h): float4 Gs[i][8 g + 4 h ..];
+        // B lane (c = l31, h): XJ[8 g + 4 h + e][c] for the same four j (e = 0..3)
+        const float* ga = &Gs[(32 * wm + l31) * GLDL + 4 * h];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          const float4 a = *reinterpret_cast<const float4*>(ga + 8 * g);
+          const float av4[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float* xb = &XJ[(8 * g + 4 * h + e) * XLDL + 64 * wn + l31];
+            dacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[e], xb[0], dacc[0], 0, 0, 0);
+            dacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[e], xb[32], dacc[1], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  if (STATS) {
+    // row direction: one cross-lane reduction per chunk, then the two column halves (wn) through LDS
+    float t0, t1, t2, t3 = 0.f;
+    t0 = PHASE == 1 ? xlane32<true>(ra0, l31) : xlane32<false>(ra0, l31);
+    t1 = xlane32<false>(ra1, l31);
+    t2 = xlane32<false>(ra2, l31);
+    if (HAS3) { float r3[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) r3[r] = ra3[HAS3 ? r : 0];
+      t3 = xlane32<false>(r3, l31); }
+    __syncthreads();
+    if ((l31 & 1) == 0) {
+      const int il = 32 * wm + row32(l31 >> 1, h);
+      float* q = &red[(wn * TB + il) * 4];
+      q[0] = t0; q[1] = t1; q[2] = t2; q[3] = t3;
+    }
+    __syncthreads();
+    if (tid < TB && i0 + tid < A) {
+      const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
+      float* o = p.P + ((long long)jbeg * A + i0 + tid) * 4;        // slot = first tile of the chunk (>= I)
+      o[0] = PHASE == 1 ? fmaxf(q0[0], q1[0]) : q0[0] + q1[0];
+      o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = q0[3] + q1[3];
+    }
+  } else if (!p.gsym) {
+    const int chunk = jbeg / p.CH;
+    float* o = p.slab + (long long)chunk * A * C;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int c = 64 * wn + 32 * b + l31;
+      if (c >= C) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ig = i0 + 32 * wm + row32(r, h);
+        if (ig < A) o[(long long)ig * C + c] = dacc[b][r];
+      }
+    }
+  }
+}
+
+// r_i = it * ||x_i||^2 (the reference shift of phase 1) and the number of valid rows.
+__global__ __launch_bounds__(256)
+void contrast_prep_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ y, int ldy, int A, int C, float it,
+                          float* __restrict__ rnorm, float* __restrict__ av) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + w; i < A; i += gridDim.x * 4) {
+    float s = 0.f;
+    for (int k = lane * 4; k < C; k += 256) { const float4 v = ldg4(X + (long long)i * ldx + k); s = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, s)))); }
+    s = dcs_wave_sum(s);
+    if (lane == 0) rnorm[i] = s * it;
+  }
+  if (blockIdx.x == 0) {
+    __shared__ float sm[4];
+    float n = 0.f;
+    for (int j = threadIdx.x; j < A; j += 256) n += y[(long long)j * ldy] >= 0.f ? 1.f : 0.f;
+    n = dcs_wave_sum(n);
+    if (lane == 0) sm[w] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) av[0] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  }
+}
+
+// Sum a row's partial slots in fixed order and derive its record.  Slots of row r (strip R = r / 64): column-direction
+// results of tiles (t, R), t < R, at slot t; row-direction results of the chunks of strip R at slots R + c * CH.
+template <int PHASE>
+__global__ __launch_bounds__(256)
+void contrast_combine_kernel(const float* __restrict__ P, const float* __restrict__ y, int ldy, const float* __restrict__ rnorm,
+                             const float* __restrict__ av, int A, int ntile, int CH, int mode, float* __restrict__ rec,
+                             float* __restrict__ loss_row) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= A) return;
+  float* rc = rec + (long long)r * REC;
+  const bool live = y[(long long)r * ldy] >= 0.f;
+  if (!live) {
+    if (PHASE == 1) {
+#pragma unroll
+      for (int e = 0; e < REC; ++e) rc[e] = 0.f;
+      loss_row[r] = 0.f;
+    }
+    return;
+  }
+  const int R = r / TB;
+  double a1 = 0.0, a2 = 0.0, a3 = 0.0, a0 = PHASE == 1 ? -3.0e38 : 0.0;
+  auto add = [&](int slot) {
+    const float4 v = ldg4(P + ((long long)slot * A + r) * 4);
+    if (PHASE == 1) a0 = fmax(a0, (double)v.x); else a0 += (double)v.x;
+    a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+  };
+  for (int t = 0; t < R; ++t) add(t);
+  for (int t = R; t < ntile; t += CH) add(t);
+  if (PHASE == 1) {
+    // n2 = sum (s - m)^2 = sum (s - r)^2 - 2 (m - r) sum (s - r) + A_v (m - r)^2, in double; 0 <= m - r <= range
+    const double dm = a0 - (double)rnorm[r];
+    double n2 = a2 - 2.0 * dm * a1 + (double)av[0] * dm * dm;
+    if (n2 < 0.0) n2 = 0.0;
+    const float nraw = (float)sqrt(n2);
+    rc[0] = (float)a0; rc[1] = 0.f; rc[2] = 1.f / fmaxf(nraw, 1e-12f); rc[7] = nraw <= 1e-12f ? 1.f : 0.f;
+  } else if (PHASE == 2) {
+    const float den = (float)a0, cnt = (float)a1, sEL = (float)a2, swL = (float)a3;
+    const float icnt = 1.f / cnt;
+    rc[3] = den; rc[4] = icnt;
+    if (mode == 1) {
+      rc[5] = 0.f; rc[6] = sEL / den - swL * icnt;
+      loss_row[r] = -(swL - cnt * logf(den)) * icnt;
+    } else {
+      rc[6] = sEL;                                                // parked until phase 3 delivers q
+    }
+  } else {
+    const float icnt = rc[4], sEL = rc[6];
+    const float lp = (float)a0, qv = (float)a1, sdl = (float)a2;
+    rc[5] = qv; rc[6] = (qv * sEL - sdl) * icnt;
+    loss_row[r] = -lp * icnt;
+  }
+}
+
+// dX[i][c] = sum over the chunk slabs (fixed order); block 0 also reduces the loss.
+__global__ __launch_bounds__(256)
+void contrast_finish_kernel(const float* __restrict__ slab, int nchunk, long long n, float* __restrict__ dX, int C, int lddx,
+                            const float* __restrict__ loss_row, const float* __restrict__ av, int A, float* __restrict__ loss) {
+  if (slab) {
+    for (long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4; e < n; e += (long long)gridDim.x * 1024) {
+      float4 s = ldg4(slab + e);
+      for (int k = 1; k < nchunk; ++k) { const float4 v = ldg4(slab + (long long)k * n + e); s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+      const long long i = e / C; const int c = (int)(e - i * C);
+      *reinterpret_cast<float4*>(&dX[i * lddx + c]) = s;
+    }
+  }
+  if (blockIdx.x == 0) {
+    __shared__ double sm[4];
+    double s = 0.0;
+    for (int j = threadIdx.x; j < A; j += 256) s += (double)loss_row[j];
+    s = dcs_wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[0] = (float)(((sm[0] + sm[1]) + (sm[2] + sm[3])) / (double)av[0]);
+  }
+}
+
+size_t strip_smem(int phase) {
+  return (size_t)(TB * XLDL + 2 * TB * REC + 4 * TB + 2 * TB * 4 + (phase == 4 ? TB * GLDL : 0)) * sizeof(float);
+}
+
+int large_ws_floats(int A, int C, int64_t* out) {
+  const int64_t ntile = (A + TB - 1) / TB;
+  // rec, loss_row, rnorm, av(+pad), P [ntile][A][4], slabs [nchunk <= 16][A][C]
+  *out = (int64_t)A * (REC + 2) + 64 + ntile * A * 4 + 16ll * A * C + 64;
+  return 0;
+}
+
+int launch_large(const float* X, int ldx, const float* y, int ldy, const float* mask, int mb, int A, int C, int mode, float it,
+                 float* loss, float* dX, int lddx, float* gsym, int ldg, float* ws, hipStream_t s) {
+  const int ntile = (A + TB - 1) / TB;
+  float* rec = ws;
+  float* loss_row = rec + (size_t)A * REC;
+  float* rnorm = loss_row + A;
+  float* av = rnorm + A;                       // 64-float slot (keeps the partials 16-B aligned)
+  float* P = av + 64 - (((size_t)A * (REC + 2)) & 3);
+  P += (4 - ((P - ws) & 3)) & 3;
+  float* slab = P + (size_t)ntile * A * 4;
+  slab += (4 - ((slab - ws) & 3)) & 3;
+  StripParams p;
+  p.X = X; p.ldx = ldx; p.y = y; p.ldy = ldy; p.mask = mask; p.mb = mb; p.A = A; p.C = C; p.mode = mode; p.ntile = ntile;
+  p.it = it; p.rnorm = rnorm; p.rec = rec; p.P = P; p.slab = slab; p.gsym = gsym; p.ldg = ldg; p.av = av;
+  // statistics sweeps: ~3 blocks per CU.  chunks per strip I = ceil((ntile - I) / CH)
+  int CH = 1;
+  for (; CH < 16; ++CH) {
+    long long nb = 0;
+    for (int I = 0; I < ntile; ++I) nb += (ntile - I + CH - 1) / CH;
+    if (nb <= 768) break;
+  }
+  long long nb_stats = 0;
+  for (int I = 0; I < ntile; ++I) nb_stats += (ntile - I + CH - 1) / CH;
+  p.CH = CH;
+#define LAUNCH_STRIP(PH, grid, block, sh, st, prm)                                                     \
+  do {                                                                                                \
+    if (mode == 0) hipLaunchKernelGGL((contrast_strip_kernel<PH, 0>), grid, block, sh, st, prm);       \
+    else hipLaunchKernelGGL((contrast_strip_kernel<PH, 1>), grid, block, sh, st, prm);                 \
+  } while (0)
+  hipLaunchKernelGGL(contrast_prep_kernel, dim3(256), dim3(256), 0, s, X, ldx, y, ldy, A, C, it, rnorm, av);
+  const dim3 cg((A + 255) / 256);
+  auto set_attr = [](const void* f, size_t sh) {
+    return sh <= 64 * 1024 || hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) == hipSuccess;
+  };
+  LAUNCH_STRIP(1, dim3((unsigned)nb_stats), dim3(256), strip_smem(1), s, p);
+  hipLaunchKernelGGL(contrast_combine_kernel<1>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
+  LAUNCH_STRIP(2, dim3((unsigned)nb_stats), dim3(256), strip_smem(2), s, p);
+  hipLaunchKernelGGL(contrast_combine_kernel<2>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
+  if (mode == 0) {
+    LAUNCH_STRIP(3, dim3((unsigned)nb_stats), dim3(256), strip_smem(3), s, p);
+    hipLaunchKernelGGL(contrast_combine_kernel<3>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
+  }
+  // final sweep: all tiles of every strip, chunked so that ~3 blocks per CU run; <= 16 dX slabs
+  int CH4 = (ntile * ntile + 767) / 768;
+  if (CH4 < (ntile + 15) / 16) CH4 = (ntile + 15) / 16;
+  if (CH4 < 1) CH4 = 1;
+  const int nchunk = (ntile + CH4 - 1) / CH4;
+  p.CH = CH4;
+  if (!set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<4, 0>), strip_smem(4)) ||
+      !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<4, 1>), strip_smem(4))) return DCS_E_LAUNCH;
+  LAUNCH_STRIP(4, dim3((unsigned)(ntile * nchunk)), dim3(256), strip_smem(4), s, p);
+  const long long n = (long long)A * C;
+  hipLaunchKernelGGL(contrast_finish_kernel, dim3(gsym ? 1u : 512u), dim3(256), 0, s, gsym ? nullptr : slab, nchunk, n, dX, C,
+                     lddx, loss_row, av, A, loss);
+#undef LAUNCH_STRIP
+  DCS_LAUNCH_RET();
+}
+
+constexpr int SMALL_MAX = 1024;
+constexpr int NW_S = 8;
+
+template <typename ACC>
+int launch_small(const float* X, int ldx, const float* y, int ldy, const float* mask, int mb, int A, int C, int mode,
+                 float it, float* loss, float* dX, int lddx, float* gsym, int ldg, float* ws, hipStream_t s) {
+  float* rec = ws;
+  float* loss_row = ws + (size_t)A * REC;
+  int AP = (A + 15) / 16 * 16;
+  AP += (20 - (AP & 31) + 32) & 31;                                   // row stride = 20 mod 32 floats
+  const size_t sh1 = (size_t)16 * AP * sizeof(ACC) + (size_t)AP * 4;
+  const int nb = (A + 15) / 16;
+  auto k1 = contrast_small_stats_kernel<ACC, NW_S>;
+  auto k2 = contrast_small_final_kernel<ACC, NW_S>;
+  if (sh1 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
+    return DCS_E_LAUNCH;
+  hipLaunchKernelGGL(k1, dim3(nb), dim3(NW_S * 64), sh1, s, X, ldx, y, ldy, mask, mb, A, C, mode, it, rec, loss_row, AP);
+  const size_t sh2 = (size_t)(16 * REC + 16 + NW_S + 4 + NW_S * 16 * 17 + 4 + NW_S * 16 * 144) * 4;
+  if (sh2 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2) != hipSuccess)
+    return DCS_E_LAUNCH;
+  hipLaunchKernelGGL(k2, dim3(nb), dim3(NW_S * 64), sh2, s, X, ldx, y, ldy, mask, mb, A, C, mode, it, rec, loss_row, loss, dX,
+                     lddx, gsym, ldg);
+  DCS_LAUNCH_RET();
+}
+
+}  // namespace
+
+extern "C" int dcs_contrast_fused_ws(int A, int C, int64_t* floats) {
+  DCS_CHECK_ARG(A > 0 && C > 0 && floats);
+  if (A > SMALL_MAX) large_ws_floats(A, C, floats);
+  else *floats = (int64_t)A * (REC + 1) + 64;
+  return DCS_OK;
+}
+
+extern "C" int dcs_contrast_fused(const float* X, int ldx, const float* y, int ldy, const float* mask, int mask_b, int A,
+                                  int C, int mode, float inv_temp, float* loss, float* dX, int lddx, float* gsym, int ldg,
+                                  float* ws, int64_t ws_floats, void* stream) {
+  DCS_CHECK_ARG(X && y && loss && ws && A > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C && ldy >= 1);
+  DCS_CHECK_ARG(mode == 0 || mode == 1);
+  DCS_CHECK_ARG(dcs_aligned16(X) && dcs_aligned16(ws) && (!mask || (mode == 1 && mask_b > 0 && A % mask_b == 0)));
+  DCS_CHECK_ARG((dX != nullptr) != (gsym != nullptr));              // exactly one output form
+  DCS_CHECK_ARG(!dX || ((lddx & 3) == 0 && lddx >= C && C <= 128 && dcs_aligned16(dX)));
+  DCS_CHECK_ARG(!gsym || ldg >= A);
+  int64_t need = 0;
+  dcs_contrast_fused_ws(A, C, &need);
+  DCS_CHECK_ARG(ws_floats >= need);
+  hipStream_t s = dcs_stream(stream);
+  if (A > SMALL_MAX) {
+    DCS_CHECK_ARG((long long)A * (C > A ? C : A) * 16 < 0x7FFFFFFFll * 4ll);
+    return launch_large(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, s);
+  }
+  if (mode == 1) return launch_small<double>(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, s);
+  return launch_small<float>(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, s);
+}

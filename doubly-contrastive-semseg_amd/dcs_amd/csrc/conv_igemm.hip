@@ -788,30 +788,30 @@ void stem_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
 __global__ __launch_bounds__(256)
 void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nsplit,
                         int accumulate, int row_len, int dst_stride) {
-  __shared__ float sm[4][64];
+  __shared__ double sm[4][64];
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
   const long long i = (long long)blockIdx.x * 64 + c;
-  float s = 0.f;
+  double s = 0.0;                      // double accumulators: up to 1024 slabs of mixed sign per element, HBM-bound kernel
   if (i < n) {
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int k = sl;
     for (; k + 12 < nsplit; k += 16) {
-      s0 += slab[(long long)k * n + i];
-      s1 += slab[(long long)(k + 4) * n + i];
-      s2 += slab[(long long)(k + 8) * n + i];
-      s3 += slab[(long long)(k + 12) * n + i];
+      s0 += (double)slab[(long long)k * n + i];
+      s1 += (double)slab[(long long)(k + 4) * n + i];
+      s2 += (double)slab[(long long)(k + 8) * n + i];
+      s3 += (double)slab[(long long)(k + 12) * n + i];
     }
-    for (; k < nsplit; k += 4) s0 += slab[(long long)k * n + i];
+    for (; k < nsplit; k += 4) s0 += (double)slab[(long long)k * n + i];
     s = (s0 + s1) + (s2 + s3);
   }
   sm[sl][c] = s;
   __syncthreads();
   if (sl == 0 && i < n) {
-    const float t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
+    const double t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
     // row_len > 0: the slab holds compact rows of row_len floats that land at stride dst_stride in dw
     // (a channel slice of a wider weight tensor, used for "virtual concat" convolutions)
     const long long o = row_len > 0 ? (i / row_len) * dst_stride + (i % row_len) : i;
-    dw[o] = (accumulate ? dw[o] : 0.f) + t;
+    dw[o] = (float)((accumulate ? (double)dw[o] : 0.0) + t);
   }
 }
 

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256)
 void bn_pool_bwd_partial_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, const float* __restrict__ y,
                                 const float* __restrict__ bn, float* __restrict__ partial, int N, int H, int W, int OH,
                                 int OW, int C, int groups) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [2][RL][C]
+  extern __shared__ __attribute__((aligned(16))) double smd[];   // [2][RL][C]; double: see colsum_partial_kernel
   const int C4 = C >> 2, RL = 256 / C4;
   const int tid = threadIdx.x, col4 = tid % C4, rl = tid / C4;
   const int c = col4 * 4;
@@ -174,7 +174,7 @@ void bn_pool_bwd_partial_kernel(const float* __restrict__ g, const uint8_t* __re
   const long long qbeg = (long long)blockIdx.x * qpg;
   const long long qend = qbeg + qpg < Q ? qbeg + qpg : Q;
   const float4 sc = ld4(bn + c), sh = ld4(bn + C + c), mu = ld4(bn + 2 * C + c), is = ld4(bn + 3 * C + c);
-  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
   for (long long q = qbeg + rl; q < qend; q += RL) {
     const int qx = (int)(q % QW);
     const long long t = q / QW;
@@ -189,19 +189,23 @@ void bn_pool_bwd_partial_kernel(const float* __restrict__ g, const uint8_t* __re
       float4 v = gq[p];
       v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
       v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
-      s0 = f4add(s0, v);
-      s1.x = fmaf(v.x, (yy.x - mu.x) * is.x, s1.x); s1.y = fmaf(v.y, (yy.y - mu.y) * is.y, s1.y);
-      s1.z = fmaf(v.z, (yy.z - mu.z) * is.z, s1.z); s1.w = fmaf(v.w, (yy.w - mu.w) * is.w, s1.w);
+      const float xh[4] = {(yy.x - mu.x) * is.x, (yy.y - mu.y) * is.y, (yy.z - mu.z) * is.z, (yy.w - mu.w) * is.w};
+      const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += d[e]; a1[e] = fma(d[e], (double)xh[e], a1[e]); }
     }
   }
-  st4(&sm[(0 * RL + rl) * C + c], s0);
-  st4(&sm[(1 * RL + rl) * C + c], s1);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    smd[(0 * RL + rl) * C + c + e] = a0[e];
+    smd[(1 * RL + rl) * C + c + e] = a1[e];
+  }
   __syncthreads();
   for (int t = tid; t < 2 * C; t += 256) {
     const int which = t / C, cc = t - which * C;
-    float s = 0.f;
-    for (int k = 0; k < RL; ++k) s += sm[(which * RL + k) * C + cc];
-    partial[((long long)blockIdx.x * 2 + which) * C + cc] = s;
+    double s = 0.0;
+    for (int k = 0; k < RL; ++k) s += smd[(which * RL + k) * C + cc];
+    partial[((long long)blockIdx.x * 2 + which) * C + cc] = (float)s;
   }
 }
 
@@ -536,7 +540,7 @@ extern "C" int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const
   DCS_CHECK_ARG(g && idx && y && bn && partial && N > 0 && H > 0 && W > 0 && groups > 0);
   DCS_CHECK_ARG(C >= 4 && C <= 1024 && (C & 3) == 0 && 256 % (C / 4) == 0);
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
-  const size_t sh = (size_t)2 * (256 / (C / 4)) * C * sizeof(float);
+  const size_t sh = (size_t)2 * (256 / (C / 4)) * C * sizeof(double);
   hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3((unsigned)groups), dim3(256), sh, dcs_stream(stream), g, idx, y, bn,
                      partial, N, H, W, OH, OW, C, groups);
   DCS_LAUNCH_RET();

@@ -126,7 +126,7 @@ class DeepLabEngine:
         rows = rows if rows is not None else x.numel() // Cc
         if training:
             if sums is None:
-                sums = ops.colsum(x.reshape(-1, Cc)[:rows])
+                sums = ops.colsum(x.reshape(-1, Cc)[:rows], moments=True)
             bn = ops.bn_finalize(sums, m.weight, m.bias, m.running_mean, m.running_var, rows, True, momentum=m.momentum)
             self._nbt.append(m)
             return bn

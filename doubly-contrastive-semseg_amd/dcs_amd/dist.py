@@ -7,8 +7,10 @@ SURVEY.md 8(e) defines the MI355X design implemented here:
     DataParallel replicas);
   * hard anchors are SAMPLED per rank (``n_view`` depends on the local class count, utils/loss.py:290-291), then
     the sampled pixel embeddings [A_r,128] (+labels) and the projected image embeddings [2B_r,128] (+labels)
-    are ALL-GATHERED so that both contrastive denominators run over the global batch.  Every rank evaluates the
-    full global loss and back-propagates only its own rows -- no collective in the backward of the losses;
+    are ALL-GATHERED -- one fixed-shape ``all_gather_into_tensor`` each, padding rows labelled -1, no count
+    exchange and no host synchronisation -- so that both contrastive denominators run over the global batch.
+    Every rank evaluates the full global loss and back-propagates only its own rows -- no collective in the
+    backward of the losses;
   * the segmentation loss is normalised by the GLOBAL count of valid pixels (all-reduce of 2 floats);
   * parameter gradients of all ranks are SUMMED with ONE all-reduce over a flat fp32 bucket (48.2 MB for
     ResNet-18: ~0.3-0.6 ms on xGMI against >=250 ms of backward, so no bucketing/overlap is needed);
@@ -26,31 +28,37 @@ import torch.distributed as dist
 
 
 class RowGather:
-    """All-gather of a variable number of [rows, C] embeddings and their labels.
+    """Fixed-shape all-gather of [rows, C] embeddings and their labels -- no count exchange, no host synchronisation.
 
-    Returns (X_all [sum A_r, C], y_all [sum A_r], start) where this rank's rows are
-    X_all[start:start+A_r], ranks concatenated in rank order."""
+    Every rank contributes ``cap`` rows of C + 4 floats: its A <= cap real rows [x_0 .. x_{C-1}, label, 0, 0, 0] followed
+    by padding rows whose label is -1, which the fused contrast kernels skip (they enter no maximum, norm, denominator,
+    loss or gradient).  One ``all_gather_into_tensor`` of [cap, C+4] per contrastive loss; ``__call__`` returns the
+    gathered buffer [world * cap, C + 4] (rows of rank r at [r * cap, (r + 1) * cap)) and this rank's first row.  The
+    caller hands the strided views buf[:, :C] / buf[:, C] straight to ``ops.contrast_fwd_bwd``.
+    ``cap`` must be the same on every rank: it is derived from the per-rank batch size (weak scaling)."""
 
     def __init__(self, group=None):
         self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
 
-    def __call__(self, X: torch.Tensor, y: torch.Tensor):
-        world = dist.get_world_size(self.group)
-        rank = dist.get_rank(self.group)
+    def instance_offset(self) -> int:
+        """SimCLR labels images by their index (class_labels=None, utils/loss.py:151-152 ``torch.eye``): indices of
+        different ranks must not collide in the gathered set, so rank r labels from r * 2**16 (exact in fp32)."""
+        return self.rank << 16
+
+    def __call__(self, X: torch.Tensor, y: torch.Tensor, cap: int):
         A, Cc = X.shape
-        cnt = torch.tensor([A], device=X.device, dtype=torch.int64)
-        cnts = [torch.zeros_like(cnt) for _ in range(world)]
-        dist.all_gather(cnts, cnt, group=self.group)
-        counts = [int(c) for c in cnts]                      # one small host sync (the sampler already synced)
-        amax = max(counts)
-        buf = torch.zeros((amax, Cc + 1), device=X.device, dtype=X.dtype)
-        buf[:A, :Cc] = X
-        buf[:A, Cc] = y
-        bufs = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(bufs, buf, group=self.group)
-        X_all = torch.cat([b[:c, :Cc] for b, c in zip(bufs, counts)], dim=0).contiguous()
-        y_all = torch.cat([b[:c, Cc] for b, c in zip(bufs, counts)], dim=0).contiguous()
-        return X_all, y_all, sum(counts[:rank])
+        if A > cap:
+            raise ValueError(f"RowGather: {A} rows exceed the per-rank capacity {cap}")
+        buf = torch.zeros((cap, Cc + 4), device=X.device, dtype=X.dtype)
+        buf[:, Cc] = -1.0
+        if A:
+            buf[:A, :Cc] = X
+            buf[:A, Cc] = y
+        out = torch.empty((self.world * cap, Cc + 4), device=X.device, dtype=X.dtype)
+        dist.all_gather_into_tensor(out, buf, group=self.group)
+        return out, self.rank * cap
 
 
 class SegLossReduce:
@@ -75,6 +83,10 @@ class DataParallelStep:
         rg = RowGather(group)
         ts.supcon_criterion.row_gather = rg
         ts.pixelcontrast_criterion.row_gather = rg
+        b_local = max(1, int(ts.opts.batch_size) // world)        # per-rank labelled images (weak scaling: equal shards)
+        ts.supcon_criterion.gather_cap = 2 * b_local
+        pc = ts.pixelcontrast_criterion
+        pc.gather_cap = min(pc.max_samples, pc.max_views * int(ts.opts.num_classes) * b_local)
         red = SegLossReduce(group)
         ts.criterion.dist_reduce = red
         ts.ce_criterion.dist_reduce = red

@@ -38,7 +38,7 @@ SIGNATURES = {
     "dcs_pack_stem_weight": [_P, _P, _I, _I, _P],
     "dcs_transpose": [_P, _P, _I, _I, _P],
     "dcs_colsum_partial": [_P, _P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _I, _P],
-    "dcs_colsum_final": [_P, _P, _I, _I, _I, _F, _P],
+    "dcs_colsum_final": [_P, _P, _I, _I, _I, _F, _D, _P],
     "dcs_bn_finalize": [_P, _P, _P, _P, _P, _P, _I, _D, _F, _F, _I, _I, _P],
     "dcs_bn_ema_again": [_P, _P, _P, _I, _D, _F, _F, _P],
     "dcs_bn_act": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
@@ -63,6 +63,8 @@ SIGNATURES = {
     "dcs_scatter_rows_bilinear": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_label_boundary_weights": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P],
     "dcs_confusion": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dcs_contrast_fused_ws": [_I, _I, C.POINTER(C.c_int64)],
+    "dcs_contrast_fused": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _I, _P, _L, _P],
     "dcs_contrast_rows": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "dcs_symmetrize": [_P, _P, _I, _I, _P],
     "dcs_sum_scalar": [_P, _P, _I, _F, _P],

@@ -206,7 +206,7 @@ def _identity_bn(Cc, dev, dtype=torch.float32):
 
 class _SupConFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, features, labels, w1, b1, w2, b2, temperature, row_gather=None):
+    def forward(ctx, features, labels, w1, b1, w2, b2, temperature, row_gather=None, cap=0, mask=None):
         v = nhwc(features.detach())
         N, H, W, Cc = v.shape
         pooled = ops.colsum(v.reshape(N * H * W, Cc), B=N, scale=1.0 / (H * W))[:, 0, :].contiguous()
@@ -215,10 +215,11 @@ class _SupConFn(torch.autograd.Function):
         a1 = ops.bn_act(h1, _identity_bn(h1.shape[1], h1.device, h1.dtype), relu=True)
         f = ops.linear(a1, w2c, b2.detach().contiguous())
         if row_gather is None:
-            loss, dF = ops.contrast_fwd_bwd(f, labels, 1, temperature)
+            loss, dF = ops.contrast_fwd_bwd(f, labels, 1, temperature, mask=mask)
         else:                                   # global-batch denominator: every rank evaluates all rows
-            f_all, y_all, start = row_gather(f, labels)
-            loss, dF_all = ops.contrast_fwd_bwd(f_all, y_all, 1, temperature)
+            buf, start = row_gather(f, labels, cap)
+            Cf = f.shape[1]
+            loss, dF_all = ops.contrast_fwd_bwd(buf[:, :Cf], buf[:, Cf], 1, temperature)
             dF = dF_all[start:start + f.shape[0]].contiguous()
         ctx.saved = (pooled, a1, dF, w1c, w2c, (N, H, W, Cc))
         return loss.reshape(()).clone()
@@ -239,7 +240,7 @@ class _SupConFn(torch.autograd.Function):
         dpool = ops.linear(dh1, ops.transpose(w1c))
         gfeat = torch.empty((N, H, W, Cc), device=dF.device, dtype=dF.dtype)
         ops.add_rowvec_bcast(gfeat, dpool, 1.0 / (H * W), accumulate=False)
-        return gfeat.permute(0, 3, 1, 2), None, dw1, db1, dw2, db2, None, None
+        return gfeat.permute(0, 3, 1, 2), None, dw1, db1, dw2, db2, None, None, None, None
 
 
 class SupConLoss(nn.Module):
@@ -260,6 +261,7 @@ class SupConLoss(nn.Module):
                                         nn.Linear(dim_in, feat_dim)).to(self.device)
         self.contrast_mode = "all"
         self.row_gather = None             # set by dcs_amd.dist.DataParallelStep
+        self.gather_cap = 0                # rows every rank contributes to the all-gather (2 x its batch)
 
     def forward(self, features, class_labels=None, mask=None):
         if features.dim() != 4:
@@ -267,11 +269,20 @@ class SupConLoss(nn.Module):
         bsz = features.shape[0] // 2
         if class_labels is not None and mask is not None:
             raise ValueError("Cannot define both `labels` and `mask`")
-        if mask is not None:
-            raise NotImplementedError("explicit `mask` is not supported by the HIP SupCon kernel")
         dev = features.device
-        if class_labels is None:
+        if mask is not None:
+            # explicit contrastive mask [bsz, bsz], mask_ij = 1 if sample j is a positive of sample i; may be asymmetric
+            # (utils/loss.py:148-159).  Single-process only: the reference has no notion of a mask across ranks.
+            if self.row_gather is not None:
+                raise ValueError("an explicit `mask` cannot be combined with the data-parallel row gather")
+            mask = mask.to(dev, torch.float32)
+            if mask.shape != (bsz, bsz):
+                raise ValueError("`mask` needs to be [bsz, bsz]")
             lab = torch.arange(bsz, device=dev, dtype=features.dtype)
+        elif class_labels is None:
+            lab = torch.arange(bsz, device=dev, dtype=features.dtype)
+            if self.row_gather is not None:           # instance ids must be unique across ranks in the gathered set
+                lab = lab + float(self.row_gather.instance_offset())
         else:
             lab = class_labels.contiguous().view(-1).to(dev, features.dtype)
             if lab.shape[0] != bsz:
@@ -281,24 +292,33 @@ class SupConLoss(nn.Module):
         if self.temperature != self.base_temperature:
             raise NotImplementedError("temperature != base_temperature")
         return _SupConFn.apply(features, lab2, p[0].weight, p[0].bias, p[2].weight, p[2].bias,
-                               float(self.temperature), self.row_gather)
+                               float(self.temperature), self.row_gather, int(self.gather_cap or 2 * bsz), mask)
 
 
 # --------------------------------------------------------------------------- #
 # pixel-level contrastive loss
 # --------------------------------------------------------------------------- #
+def _contrast_rows(X, y, temperature, row_gather, cap):
+    """Pixel-contrast loss of the sampled rows X [A,C] (A may be 0 on a data-parallel rank whose shard holds no class
+    with enough pixels: it then contributes only padding to the gather and receives a zero gradient)."""
+    if row_gather is None:
+        return ops.contrast_fwd_bwd(X, y, 0, temperature)
+    buf, start = row_gather(X, y, cap)
+    Cc = X.shape[1]
+    loss, dX_all = ops.contrast_fwd_bwd(buf[:, :Cc], buf[:, Cc], 0, temperature)
+    return loss, dX_all[start:start + X.shape[0]].contiguous()
+
+
 class _PixelContrastFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, rowidx, y, temperature, row_gather=None):
+    def forward(ctx, feats, rowidx, y, temperature, row_gather=None, cap=0):
         v = nhwc(feats.detach())
         N, H, W, Cc = v.shape
-        X = ops.gather_rows(v.reshape(N * H * W, Cc), rowidx)
-        if row_gather is None:
-            loss, dX = ops.contrast_fwd_bwd(X, y, 0, temperature)
+        if rowidx.numel():
+            X = ops.gather_rows(v.reshape(N * H * W, Cc), rowidx)
         else:
-            X_all, y_all, start = row_gather(X, y)
-            loss, dX_all = ops.contrast_fwd_bwd(X_all, y_all, 0, temperature)
-            dX = dX_all[start:start + X.shape[0]].contiguous()
+            X = torch.empty((0, Cc), device=v.device, dtype=v.dtype)
+        loss, dX = _contrast_rows(X, y, temperature, row_gather, cap)
         ctx.saved = (dX, rowidx, (N, H, W, Cc))
         return loss.reshape(()).clone()
 
@@ -306,10 +326,11 @@ class _PixelContrastFn(torch.autograd.Function):
     def backward(ctx, g):
         dX, rowidx, (N, H, W, Cc) = ctx.saved
         ctx.saved = None
-        ops.scale_inplace(dX, _scalar(g))
         gfeat = torch.zeros((N, H, W, Cc), device=dX.device, dtype=dX.dtype)
-        ops.scatter_add_rows(dX, rowidx, gfeat)
-        return gfeat.permute(0, 3, 1, 2), None, None, None, None
+        if rowidx.numel():
+            ops.scale_inplace(dX, _scalar(g))
+            ops.scatter_add_rows(dX, rowidx, gfeat)
+        return gfeat.permute(0, 3, 1, 2), None, None, None, None, None
 
 
 class LazyUpsampled:
@@ -338,15 +359,13 @@ class LazyUpsampled:
 
 class _PixelContrastLazyFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, lowres, rowidx, y, temperature, row_gather, size):
+    def forward(ctx, lowres, rowidx, y, temperature, row_gather, size, cap=0):
         v = nhwc(lowres.detach())
-        X = ops.gather_rows_bilinear(v, rowidx, size[0], size[1])
-        if row_gather is None:
-            loss, dX = ops.contrast_fwd_bwd(X, y, 0, temperature)
+        if rowidx.numel():
+            X = ops.gather_rows_bilinear(v, rowidx, size[0], size[1])
         else:
-            X_all, y_all, start = row_gather(X, y)
-            loss, dX_all = ops.contrast_fwd_bwd(X_all, y_all, 0, temperature)
-            dX = dX_all[start:start + X.shape[0]].contiguous()
+            X = torch.empty((0, v.shape[-1]), device=v.device, dtype=v.dtype)
+        loss, dX = _contrast_rows(X, y, temperature, row_gather, cap)
         ctx.saved = (dX, rowidx, tuple(v.shape), size)
         return loss.reshape(()).clone()
 
@@ -354,10 +373,11 @@ class _PixelContrastLazyFn(torch.autograd.Function):
     def backward(ctx, g):
         dX, rowidx, shape, size = ctx.saved
         ctx.saved = None
-        ops.scale_inplace(dX, _scalar(g))
         gfeat = torch.zeros(shape, device=dX.device, dtype=dX.dtype)
-        ops.scatter_rows_bilinear(dX, rowidx, gfeat, size[0], size[1])
-        return gfeat.permute(0, 3, 1, 2), None, None, None, None, None
+        if rowidx.numel():
+            ops.scale_inplace(dX, _scalar(g))
+            ops.scatter_rows_bilinear(dX, rowidx, gfeat, size[0], size[1])
+        return gfeat.permute(0, 3, 1, 2), None, None, None, None, None, None
 
 
 def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):
@@ -433,6 +453,7 @@ class PixelContrastLoss(nn.Module, ABC):
         self.contrast_mode = "all"
         self.last_anchors = None          # (img [T], cls [T], pix [T, n_view]) of the last call, for tests
         self.row_gather = None            # set by dcs_amd.dist.DataParallelStep
+        self.gather_cap = 0               # rows every rank contributes to the all-gather (<= max_samples)
 
     def _count(self, feats, labels, predict):
         """Device half of the sampler (argmax, nearest label downsample, per-class hard/easy histogram) and the
@@ -475,22 +496,31 @@ class PixelContrastLoss(nn.Module, ABC):
             pre["event"].synchronize()                        # one host wait per step (reference: ~3 per class)
         counts = pre["counts"]
         plan = plan_anchor_requests(counts, nc, self.max_samples, self.max_views)
-        if plan is None:
-            raise AttributeError("'NoneType' object has no attribute 'shape'")   # loss.py:341 on (None, None)
-        n_view, T, req, cls, img = plan
-        HW = h * w
-        # view-major anchor order of torch.cat(torch.unbind(X_, dim=1)) (loss.py:347): a = v*T + t
-        order = [t * n_view + v for v in range(n_view) for t in range(T)]
-        req_vm = [req[i] for i in order]
-        host = torch.tensor([r + [r[0] * HW] for r in req_vm], dtype=torch.int32)
-        dev = host.to(feats.device, non_blocking=False)
-        pix = ops.anchor_select(key, hist, dev[:, :3].contiguous(), nc)
-        rowidx = (pix + dev[:, 3]).contiguous()
-        y = torch.tensor([float(cls[t]) for _ in range(n_view) for t in range(T)], dtype=feats.dtype).to(feats.device)
-        self.last_anchors = (img, cls, pix.view(n_view, T), n_view)
         if self.temperature != self.base_temperature:
             raise NotImplementedError("temperature != base_temperature")
+        cap = int(self.gather_cap or self.max_samples)
+        if plan is None:
+            if self.row_gather is None:
+                raise AttributeError("'NoneType' object has no attribute 'shape'")   # loss.py:341 on (None, None)
+            # data parallel: THIS rank's shard has no class with enough pixels, the global batch may well have.  The rank
+            # must still take part in the collective (the others are waiting in it): it contributes padding only, gets
+            # the global loss and a zero gradient.  (All ranks empty -> NaN loss: 0 valid rows, like an empty mean.)
+            rowidx = torch.empty((0,), device=feats.device, dtype=torch.int32)
+            y = torch.empty((0,), device=feats.device, dtype=torch.float32)
+            self.last_anchors = ([], [], torch.empty((0, 0), device=feats.device, dtype=torch.int32), 0)
+        else:
+            n_view, T, req, cls, img = plan
+            HW = h * w
+            # view-major anchor order of torch.cat(torch.unbind(X_, dim=1)) (loss.py:347): a = v*T + t
+            order = [t * n_view + v for v in range(n_view) for t in range(T)]
+            req_vm = [req[i] for i in order]
+            host = torch.tensor([r + [r[0] * HW] for r in req_vm], dtype=torch.int32)
+            dev = host.to(feats.device, non_blocking=False)
+            pix = ops.anchor_select(key, hist, dev[:, :3].contiguous(), nc)
+            rowidx = (pix + dev[:, 3]).contiguous()
+            y = torch.tensor([float(cls[t]) for _ in range(n_view) for t in range(T)], dtype=torch.float32).to(feats.device)
+            self.last_anchors = (img, cls, pix.view(n_view, T), n_view)
         if isinstance(feats, LazyUpsampled):
             return _PixelContrastLazyFn.apply(feats.lowres, rowidx, y, float(self.temperature), self.row_gather,
-                                              feats.size)
-        return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature), self.row_gather)
+                                              feats.size, cap)
+        return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature), self.row_gather, cap)

@@ -161,16 +161,20 @@ def _stats_buffer(M, Cout, dev):
     return torch.zeros((G1 * 128, 2, Cout), device=dev, dtype=_F32), G, G1
 
 
-def _stats_reduce(part, G, G1, Cout):
-    """-> sums [1, 2, Cout] (sum, sum of squares) over all rows, deterministic."""
+class Moments(torch.Tensor):
+    """[1,2,C] tensor holding (mean, biased variance) instead of (sum, sum of squares): see bn_finalize."""
+
+
+def _stats_reduce(part, G, G1, Cout, count):
+    """-> Moments [1, 2, Cout] = (mean, biased variance) over all ``count`` rows, formed in double (deterministic)."""
     out = torch.empty((1, 2, Cout), device=part.device, dtype=_F32)
     if G1 == 0:
-        _call("dcs_colsum_final", _p(part), _p(out), 1, G, Cout, 1.0, _stream())
+        _call("dcs_colsum_final", _p(part), _p(out), 1, G, Cout, 1.0, float(count), _stream())
     else:
         mid = torch.empty((G1, 2, Cout), device=part.device, dtype=_F32)
-        _call("dcs_colsum_final", _p(part), _p(mid), G1, 128, Cout, 1.0, _stream())
-        _call("dcs_colsum_final", _p(mid), _p(out), 1, G1, Cout, 1.0, _stream())
-    return out
+        _call("dcs_colsum_final", _p(part), _p(mid), G1, 128, Cout, 1.0, 0.0, _stream())
+        _call("dcs_colsum_final", _p(mid), _p(out), 1, G1, Cout, 1.0, float(count), _stream())
+    return out.as_subclass(Moments)
 
 
 def _ksplit(g, M, Cout):
@@ -217,13 +221,13 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1,
     y = alloc((N, g.DH, g.DW, cs), device=x.device, dtype=_F32)
     if ns > 1:
         _gather_split(x, krsc(w), g, ns, y, False)
-        return (y, colsum(y.reshape(-1, Cout))) if want_stats else y
+        return (y, colsum(y.reshape(-1, Cout), moments=True)) if want_stats else y
     if not want_stats:
         _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, None, _stream())
         return y
     part, G, G1 = _stats_buffer(N * g.DH * g.DW, Cout, x.device)
     _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, _p(part), _stream())
-    return y, _stats_reduce(part, G, G1, Cout)
+    return y, _stats_reduce(part, G, G1, Cout, N * g.DH * g.DW)
 
 
 def pack_dgrad_weight(w, koff=0, kw=None):
@@ -327,7 +331,7 @@ def stem_conv(p, wp, want_stats=False):
         return y
     part, G, G1 = _stats_buffer(N * g.DH * g.DW, 64, p.device)
     _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, _p(part), _stream())
-    return y, _stats_reduce(part, G, G1, 64)
+    return y, _stats_reduce(part, G, G1, 64, N * g.DH * g.DW)
 
 
 def stem_wgrad(p, dy, dwp, accumulate):
@@ -378,8 +382,9 @@ def _groups(rows):
     return int(max(1, min(1024, rows // 64)))
 
 
-def colsum(x2d, B=1, scale=1.0):
-    """x2d [B*rows, C(strided)] -> sums [B,2,C] (sum, sum of squares) * scale."""
+def colsum(x2d, B=1, scale=1.0, moments=False):
+    """x2d [B*rows, C(strided)] -> sums [B,2,C] (sum, sum of squares) * scale; moments=True: (mean, biased variance)
+    over the rows, formed in double (a ``Moments`` tensor for bn_finalize)."""
     _req(x2d)
     total, Cc = x2d.shape
     rows = total // B
@@ -387,17 +392,18 @@ def colsum(x2d, B=1, scale=1.0):
     part = torch.empty((B, grp, 2, Cc), device=x2d.device, dtype=_F32)
     _call("dcs_colsum_partial", _p(x2d), None, None, None, _p(part), B, rows, Cc, Cc, grp, 0, 0, _stream())
     out = torch.empty((B, 2, Cc), device=x2d.device, dtype=_F32)
-    _call("dcs_colsum_final", _p(part), _p(out), B, grp, Cc, float(scale), _stream())
-    return out
+    _call("dcs_colsum_final", _p(part), _p(out), B, grp, Cc, float(scale), float(rows) if moments else 0.0, _stream())
+    return out.as_subclass(Moments) if moments else out
 
 
 def bn_finalize(sums, gamma, beta, rm, rv, count, training, repeats=1, eps=1e-5, momentum=0.1, update=True):
     Cc = gamma.shape[0]
     bn = torch.empty((4, Cc), device=gamma.device, dtype=_F32)
     upd = training and update
+    mode = (2 if isinstance(sums, Moments) else 1) if training else 0
     _call("dcs_bn_finalize", _p(sums), _p(gamma), _p(beta), _p(rm) if (upd or not training) else None,
           _p(rv) if (upd or not training) else None, _p(bn), Cc, float(count), eps, momentum, repeats,
-          1 if training else 0, _stream())
+          mode, _stream())
     return bn
 
 
@@ -424,7 +430,7 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
     _call("dcs_colsum_partial", _p(g), _p(y), _p(masksrc), _p(bn), _p(part), 1, rows, Cc, Cc, grp, 1,
           1 if relu else 0, _stream())
     sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
-    _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, _stream())
+    _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, 0.0, _stream())
     dy = None
     if want_dy:
         dy = dy_out if dy_out is not None else torch.empty_like(y)
@@ -488,7 +494,7 @@ def bn_pool_bwd(g, idx, y, bn, gamma, dgamma=None, dbeta=None, acc_param=False, 
     part = torch.empty((grp, 2, Cc), device=y.device, dtype=_F32)
     _call("dcs_bn_pool_bwd_partial", _p(g), _p(idx), _p(y), _p(bn), _p(part), N, H, W, Cc, grp, _stream())
     sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
-    _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, _stream())
+    _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, 0.0, _stream())
     dy = torch.empty_like(y)
     _call("dcs_bn_pool_bwd_apply", _p(g), _p(idx), _p(y), _p(bn), _p(gamma), _p(sums), _p(dy), _p(dgamma), _p(dbeta),
           N, H, W, Cc, 1 if acc_param else 0, 1 if training else 0, _stream())
@@ -609,15 +615,55 @@ def scatter_rows_bilinear(gX, rowidx, gfeat, OH, OW):
           _stream())
 
 
-def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
-    """Contrastive loss on anchors X [A,C] (view-major) with float labels [A].
+def contrast_fwd_bwd(X, labels, mode, temperature=0.07, mask=None):
+    """Contrastive loss on anchors X [A,C] (view-major) with float labels [A]; forward and backward fused, the
+    similarity matrix is never written (dcs_contrast_fused).
 
-    mode 0: pixel contrast (utils/loss.py:339-389); 1: SupCon/SimCLR (:175-204).
-    Returns (loss scalar tensor [1], dX [A,C] = d loss / d X)."""
+    mode 0: pixel contrast (utils/loss.py:339-389); 1: SupCon/SimCLR (:175-204).  X may be a row-strided view
+    (X.stride(1) == 1, X.stride(0) % 4 == 0) and labels a strided 1-D view -- e.g. columns of the packed all-gather
+    buffer of the data-parallel step; rows with label < 0 are padding.  mask: optional explicit [b,b] positive weights
+    (SupConLoss(mask=...), mode 1).  Returns (loss [1], dX [A,C] = d loss / d X)."""
+    if not (X.is_cuda and X.dtype == _F32 and X.dim() == 2 and X.stride(1) == 1 and X.stride(0) % 4 == 0):
+        raise RuntimeError("contrast_fwd_bwd needs a fp32 device matrix with unit column stride (no CPU fallback)")
+    if not (labels.is_cuda and labels.dtype == _F32 and labels.dim() == 1):
+        raise RuntimeError("contrast_fwd_bwd: labels must be a 1-D fp32 device tensor")
+    A, Cc = X.shape
+    ldx, ldy = X.stride(0), labels.stride(0) if A > 1 else 1
+    mb = 0
+    if mask is not None:
+        mask = _req(mask.to(_F32).contiguous())
+        mb = mask.shape[0]
+        assert mode == 1 and mask.shape == (mb, mb) and A % mb == 0
+    need = C.c_int64(0)
+    _call("dcs_contrast_fused_ws", A, Cc, C.byref(need))
+    ws = torch.empty((need.value,), device=X.device, dtype=_F32)
+    loss = torch.empty((1,), device=X.device, dtype=_F32)
+    it = 1.0 / temperature
+    if Cc <= 128:
+        dX = torch.empty((A, Cc), device=X.device, dtype=_F32)
+        _call("dcs_contrast_fused", _p(X), ldx, _p(labels), ldy, _p(mask), mb, A, Cc, mode, it, _p(loss), _p(dX), Cc, None, 0,
+              _p(ws), need.value, _stream())
+        return loss, dX
+    # wide features (DeepLab's 2048-channel pixel contrast): the kernel hands back Gs = G + G^T [A, ld] and dX = Gs X is
+    # one GEMM with K = ld (zero padded), weights X^T
+    ld = -(-A // 32) * 32
+    Gs = torch.zeros((A, ld), device=X.device, dtype=_F32) if ld != A else torch.empty((A, ld), device=X.device, dtype=_F32)
+    _call("dcs_contrast_fused", _p(X), ldx, _p(labels), ldy, _p(mask), mb, A, Cc, mode, it, _p(loss), None, 0, _p(Gs), ld,
+          _p(ws), need.value, _stream())
+    Xp = torch.zeros((ld, Cc), device=X.device, dtype=_F32)
+    Xp[:A].copy_(X)
+    Xt = transpose(Xp)                                   # [C, ld]
+    g2 = geom_fwd(A, 1, 1, ld, Cc, 1, 1, 1, 0)
+    dX = torch.empty((A, Cc), device=X.device, dtype=_F32)
+    _call("dcs_conv_gather", _p(Gs), _p(Xt), None, _p(dX), C.byref(g2), 0, None, _stream())
+    return loss, dX
+
+
+def contrast_fwd_bwd_unfused(X, labels, mode, temperature=0.07):
+    """The round-1 form (GEMM writes S, row kernel, symmetrize, GEMM): kept only as the A/B baseline of bench.py."""
     _req(X)
     A, Cc = X.shape
     ld = -(-A // 32) * 32
-    # S = X X^T on the MFMA GEMM (1x1 conv with the anchors as weights)
     g = geom_fwd(A, 1, 1, Cc, A, 1, 1, 1, 0, None, ld)
     S = torch.empty((A, ld), device=X.device, dtype=_F32)
     _call("dcs_conv_gather", _p(X), _p(X), None, _p(S), C.byref(g), 0, None, _stream())
@@ -629,13 +675,9 @@ def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
     Gs = torch.empty((A, ld), device=X.device, dtype=_F32)
     _call("dcs_symmetrize", _p(G), _p(Gs), A, ld, _stream())
     if A > 1024:
-        # dX = (G + G^T) X.  Gs is symmetric, so dX[i] = sum_j Gs[j][i] X[j]: a "weight gradient" GEMM (reduction over
-        # the rows j, split over row ranges), which fills the chip where the row-tiled form has only A/128 blocks
-        # (the gathered global batch of the data-parallel step: A up to 4864).
         dXp = torch.empty((ld, Cc), device=X.device, dtype=_F32)
         linear_wgrad(X, Gs, dXp)
         return loss, dXp[:A]
-    # per-rank size (A <= 608): launch-latency bound either way; row-tiled GEMM with K = ld (zero padded), weights X^T
     Xp = X
     if ld != A:
         Xp = torch.zeros((ld, Cc), device=X.device, dtype=_F32)

@@ -105,11 +105,15 @@ int dcs_transpose(const float* in, float* out, int R, int C, void* stream);
 int dcs_colsum_partial(const float* x, const float* y, const float* masksrc, const float* bn,
                        float* partial, int B, int64_t rows, int C, int cstride, int groups,
                        int mode, int relu, void* stream);
-/* out[b][2][C] = sum over groups, accumulated in double, times scale. */
-int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale, void* stream);
+/* out[b][2][C] = sum over groups, accumulated in double, times scale.
+ * moments_count > 0 (needs scale == 1): out[b][0][c] = mean = sum/count, out[b][1][c] = biased variance
+ * = sumsq/count - mean^2, both formed in double before the single rounding to fp32 (dcs_bn_finalize training = 2). */
+int dcs_colsum_final(const float* partial, float* out, int B, int groups, int C, float scale, double moments_count,
+                     void* stream);
 /* From sums[2][C] over `count` rows: bn[0..4C) = scale, shift, mean, invstd; updates running
  * mean/var `repeats` times (momentum, unbiased variance) when running_mean != null.
- * training = 0: ignores sums and derives scale/shift from the running statistics.            */
+ * training = 0: ignores sums and derives scale/shift from the running statistics.
+ * training = 2: sums holds (mean, biased variance) from dcs_colsum_final(moments_count = count).  */
 int dcs_bn_finalize(const float* sums, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float* bn, int C, double count, float eps, float momentum,
                     int repeats, int training, void* stream);
@@ -207,7 +211,24 @@ int dcs_gather_rows_bilinear(const float* feat, const int32_t* rowidx, float* X,
                              int OH, int OW, void* stream);
 int dcs_scatter_rows_bilinear(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, int N, int IH, int IW,
                               int OH, int OW, void* stream);
-/* ---- contrastive rows (utils/loss.py:175-204 and :361-386) -----------------------------------
+/* ---- fused similarity / InfoNCE loss (utils/loss.py:339-389 PixelContrastLoss._contrastive = mode 0,
+ *      utils/loss.py:175-204 SupConLoss = mode 1), forward AND backward, S = X X^T never written -----------------
+ * X [A][ldx] anchors (C <= ldx channels used, ldx % 4 == 0), y[i*ldy] float labels; y < 0 marks a padding row (fixed-
+ * shape all-gather of the data-parallel step): it contributes to no maximum, norm, denominator, loss or gradient.
+ * mask (nullable, mode 1 only): explicit [mask_b][mask_b] positive weights tiled over the views like
+ * mask.repeat(anchor_count, contrast_count) (utils/loss.py:148-159, :183); otherwise positives = equal labels, j != i.
+ * loss[0] = mean over the valid rows.  Exactly one of:
+ *   dX [A][lddx] = d loss / d X = (G + G^T) X            (C <= 128), or
+ *   gsym [A][ldg] = G + G^T, G_ij = d loss / d S_ij      (any C; the caller finishes dX with one GEMM).
+ * ws: scratch of dcs_contrast_fused_ws(A, C) floats.  A <= 1024: two launches (row statistics with the S strip resident in
+ * LDS; final sweep recomputing S tiles on the matrix cores); larger A: symmetric tile sweeps (see contrast_fused.hip).
+ * Rows without positives give NaN like the reference. */
+int dcs_contrast_fused_ws(int A, int C, int64_t* floats);
+int dcs_contrast_fused(const float* X, int ldx, const float* y, int ldy, const float* mask, int mask_b, int A, int C,
+                       int mode, float inv_temp, float* loss, float* dX, int lddx, float* gsym, int ldg, float* ws,
+                       int64_t ws_floats, void* stream);
+
+/* ---- contrastive rows, unfused form (kept for A/B measurements in bench.py; not used by the product path) --------
  * S [A,ld] = C C^T (from dcs_conv_gather in 1x1 mode), scaled by inv_temp = 1/T on read.  For every row i < A:
  *   max-subtract, L2-normalise, masked exp/log reductions; loss_row[i]; G[i][j] = d(mean loss)/dS_ij
  * (w.r.t. the unscaled S, already divided by the number of rows A).  labels: float [A].  mode 0: pixel contrast

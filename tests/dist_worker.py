@@ -1,4 +1,7 @@
-"""Worker for tests/test_dist_cpu.py: one rank of a world_size-2 gloo job on CPU with emulated kernels."""
+"""One rank of a world_size-2 gloo job running the data-parallel step (dcs_amd/dist.py).
+CPU (tests/test_dist_cpu.py): kernels emulated (tests/emu_ops.py).  GPU (tests/test_dist_gpu.py, DCS_DIST_DEVICE=cuda):
+the REAL kernels, both ranks sharing cuda:0 (gloo moves the device tensors; the production job uses RCCL, one rank per
+GPU -- a single GPU cannot host two RCCL ranks)."""
 import os
 import sys
 
@@ -10,16 +13,18 @@ for p in (ROOT, os.path.join(ROOT, "doubly-contrastive-semseg_amd"), os.path.joi
     if p not in sys.path:
         sys.path.insert(0, p)
 
+DEVICE = os.environ.get("DCS_DIST_DEVICE", "cpu")
+
 
 class _MP:
     def setattr(self, obj, name, val):
         setattr(obj, name, val)
 
 
-def build(criterion, global_batch, cw):
+def build(criterion, global_batch, cw, device=None):
     from dcs_amd.trainer import TrainStep, make_opts
     from oracle import swiftnet_oracle as O
-    ts = TrainStep(make_opts(criterion=criterion, batch_size=global_batch), class_weight=cw, device="cpu")
+    ts = TrainStep(make_opts(criterion=criterion, batch_size=global_batch), class_weight=cw, device=device or DEVICE)
     ts.model.load_state_dict(O.make_state(seed=1), strict=True)
     with torch.no_grad():
         p = ts.supcon_criterion.projection
@@ -34,9 +39,16 @@ def shard_sample(batch, lo, hi, two, B):
     return (s0, dict(left=img[B + lo:B + hi])) if two else s0
 
 
+def cpu(t):
+    return t.detach().cpu().contiguous().clone()
+
+
 def main(rank, world, port, outdir):
-    import emu_ops
-    emu_ops.install(_MP())
+    if DEVICE == "cpu":
+        import emu_ops
+        emu_ops.install(_MP())
+    else:
+        torch.cuda.set_device(0)
     import dcs_amd.ops as ops
     from dcs_amd.dist import DataParallelStep
     from oracle import swiftnet_oracle as O
@@ -52,29 +64,60 @@ def main(rank, world, port, outdir):
     ts.model.eval()
     dp = DataParallelStep(ts, rank, world)
     out = dp.step(shard_sample(batch, rank, rank + 1, True, B))
-    res["A_total"] = out["total"].detach().reshape(()).clone()
-    res["A_grads"] = {k: p.grad.detach().contiguous().clone() for k, p in ts.model.named_parameters() if p.grad is not None}
-    res["A_params"] = {k: p.detach().contiguous().clone() for k, p in ts.model.named_parameters()}
+    res["A_total"] = cpu(out["total"].reshape(()))
+    res["A_grads"] = {k: cpu(p.grad) for k, p in ts.model.named_parameters() if p.grad is not None}
+    res["A_params"] = {k: cpu(p) for k, p in ts.model.named_parameters()}
     # ---- scenario B: training-mode, doubly-contrastive, per-rank sampling + global denominators
     captured = []
     orig = ops.contrast_fwd_bwd
-    def spy(X, y, mode, temperature=0.07):
-        captured.append((X.detach().clone(), y.detach().clone(), mode))
-        return orig(X, y, mode, temperature)
+    def spy(X, y, mode, temperature=0.07, mask=None):
+        valid = (y >= 0).cpu()
+        captured.append((cpu(X)[valid], cpu(y)[valid], mode, int(X.shape[0])))
+        return orig(X, y, mode, temperature, mask=mask)
     ops.contrast_fwd_bwd = spy
     batch = O.synthetic_batch(B, h, w, seed=43, two_crops=True, cell=32)
     ts = build("supcon_pixelcontrast_focal", B, batch[4])
     dp = DataParallelStep(ts, rank, world)
     torch.manual_seed(100 + rank)
     out = dp.step(shard_sample(batch, rank, rank + 1, True, B))
-    ops.contrast_fwd_bwd = orig
     for k in ("total", "supcon", "pixel", "seg"):
-        res["B_" + k] = out[k].detach().reshape(()).clone()
-    res["B_pixel_rows"] = captured[1][0] if captured[1][2] == 0 else captured[0][0]
-    res["B_pixel_labels"] = captured[1][1] if captured[1][2] == 0 else captured[0][1]
+        res["B_" + k] = cpu(out[k].reshape(()))
+    pix = [c for c in captured if c[2] == 0][0]
+    res["B_pixel_rows"], res["B_pixel_labels"], res["B_gathered_rows"] = pix[0], pix[1], torch.tensor(pix[3])
     res["B_local_anchor_count"] = torch.tensor(len(ts.pixelcontrast_criterion.last_anchors[1]) *
                                                ts.pixelcontrast_criterion.last_anchors[3])
-    res["B_param_checksum"] = torch.stack([p.detach().double().sum() for p in ts.model.parameters()])
+    res["B_param_checksum"] = torch.stack([cpu(p).double().sum() for p in ts.model.parameters()])
+    # ---- scenario C: SimCLR image contrast (class_labels=None): instance ids must stay unique across ranks; with
+    #      eval-mode BatchNorm the DP loss and gradients equal the single-process run on the union batch
+    captured.clear()
+    batch = O.synthetic_batch(B, h, w, seed=45, two_crops=True, cell=32)
+    ts = build("supcon_simclr_focal", B, batch[4])
+    ts.model.eval()
+    dp = DataParallelStep(ts, rank, world)
+    out = dp.step(shard_sample(batch, rank, rank + 1, True, B))
+    res["C_total"], res["C_simclr"] = cpu(out["total"].reshape(())), cpu(out["simclr"].reshape(()))
+    res["C_labels"] = [c for c in captured if c[2] == 1][0][1]
+    res["C_grads"] = {k: cpu(p.grad) for k, p in ts.model.named_parameters() if p.grad is not None}
+    res["C_proj_grads"] = [cpu(p.grad) for p in ts.supcon_criterion.projection.parameters()]
+    # ---- scenario D: rank 1's shard is all "ignore": its sampler finds no class, it must still join the collectives
+    #      (no hang), report the global pixel loss and get a zero pixel gradient
+    captured.clear()
+    batch = list(O.synthetic_batch(B, h, w, seed=47, two_crops=False, cell=32))
+    batch[1] = batch[1].clone()
+    batch[1][1] = 255
+    batch[2] = batch[2].clone()
+    batch[2][1] = 0.0
+    ts = build("pixelcontrast_focal", B, batch[4])
+    dp = DataParallelStep(ts, rank, world)
+    torch.manual_seed(7 + rank)
+    out = dp.step(shard_sample(tuple(batch), rank, rank + 1, False, B))
+    res["D_pixel"], res["D_seg"], res["D_total"] = (cpu(out[k].reshape(())) for k in ("pixel", "seg", "total"))
+    pix = [c for c in captured if c[2] == 0][0]
+    res["D_pixel_rows"], res["D_pixel_labels"] = pix[0], pix[1]
+    res["D_local_anchor_count"] = torch.tensor(len(ts.pixelcontrast_criterion.last_anchors[1]) *
+                                               ts.pixelcontrast_criterion.last_anchors[3])
+    res["D_param_checksum"] = torch.stack([cpu(p).double().sum() for p in ts.model.parameters()])
+    ops.contrast_fwd_bwd = orig
     torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()

@@ -37,7 +37,7 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1,
     if out is not None:
         out[..., :y.shape[-1]].add_(y)
         return out
-    sums = colsum(y.reshape(-1, y.shape[-1])) if want_stats else None
+    sums = colsum(y.reshape(-1, y.shape[-1]), moments=True) if want_stats else None
     if dst_cs and dst_cs != y.shape[-1]:
         y = F.pad(y, (0, dst_cs - y.shape[-1]))
     return (y.contiguous(), sums) if want_stats else y.contiguous()
@@ -92,7 +92,7 @@ def _stem_w(wp):
 
 def stem_conv(p, wp, want_stats=False):
     y = _nhwc(F.conv2d(_nchw(p[..., :3]), _stem_w(wp), None, 2, 3))
-    return (y, colsum(y.reshape(-1, 64))) if want_stats else y
+    return (y, colsum(y.reshape(-1, 64), moments=True)) if want_stats else y
 
 
 def stem_wgrad(p, dy, dwp, accumulate):
@@ -120,16 +120,25 @@ def linear_wgrad(x, dy, dw, accumulate=False):
         dw.copy_(g)
 
 
-def colsum(x2d, B=1, scale=1.0):
+def colsum(x2d, B=1, scale=1.0, moments=False):
+    from dcs_amd.ops import Moments
     total, C = x2d.shape
     v = x2d.reshape(B, total // B, C).double()
+    if moments:
+        m = v.mean(1)
+        return torch.stack([m, ((v * v).mean(1) - m * m).clamp_min(0)], dim=1).to(x2d.dtype).as_subclass(Moments)
     return (torch.stack([v.sum(1), (v * v).sum(1)], dim=1) * scale).to(x2d.dtype)
 
 
 def bn_finalize(sums, gamma, beta, rm, rv, count, training, repeats=1, eps=1e-5, momentum=0.1, update=True):
     if training:
-        mean = sums[0, 0].double() / count
-        var = (sums[0, 1].double() / count - mean * mean).clamp_min(0)
+        from dcs_amd.ops import Moments
+        if isinstance(sums, Moments):
+            sums = sums.as_subclass(torch.Tensor)
+            mean, var = sums[0, 0].double(), sums[0, 1].double()
+        else:
+            mean = sums[0, 0].double() / count
+            var = (sums[0, 1].double() / count - mean * mean).clamp_min(0)
         invstd = 1.0 / torch.sqrt(var + eps)
         if update:
             vu = (var * (count / max(count - 1, 1))).to(rm.dtype)
@@ -341,22 +350,34 @@ def scatter_rows_bilinear(gX, rowidx, gfeat, OH, OW):
 
 
 @torch.enable_grad()
-def contrast_fwd_bwd(X, labels, mode, temperature=0.07):
-    x = X.detach().clone().requires_grad_(True)
+def contrast_fwd_bwd(X, labels, mode, temperature=0.07, mask=None):
+    """utils/loss.py:339-389 (mode 0) / :175-204 (mode 1) by autograd.  Rows with label < 0 are padding (the fixed-shape
+    all-gather of the data-parallel step): dropped here, their gradient rows are zero.  mask: explicit [b,b] positive
+    weights tiled over the views like ``mask.repeat(anchor_count, contrast_count)``."""
+    valid = labels >= 0
+    x = X.detach()[valid].clone().requires_grad_(True)
+    y = labels[valid]
     A = x.shape[0]
     s = (x @ x.t()) / temperature
     s = s - s.max(1, keepdim=True)[0].detach()
     L = F.normalize(s)
-    same = (labels.view(-1, 1) == labels.view(1, -1)).to(x.dtype)
+    same = (y.view(-1, 1) == y.view(1, -1)).to(x.dtype)
     off = 1.0 - torch.eye(A, dtype=x.dtype)
-    pos = same * off
+    if mask is not None:
+        assert mode == 1 and bool(valid.all())
+        rep = A // mask.shape[0]
+        pos = mask.to(x.dtype).repeat(rep, rep) * off
+    else:
+        pos = same * off
     if mode == 0:
         neg = (torch.exp(L) * (1 - same)).sum(1, keepdim=True)
         lp = L - torch.log(torch.exp(L) + neg)
     else:
         lp = L - torch.log((torch.exp(L) * off).sum(1, keepdim=True))
     loss = (-(pos * lp).sum(1) / pos.sum(1)).mean()
-    (dX,) = torch.autograd.grad(loss, x)
+    (dx,) = torch.autograd.grad(loss, x)
+    dX = torch.zeros_like(X)
+    dX[valid] = dx
     return loss.detach().reshape(1), dX.contiguous()
 
 

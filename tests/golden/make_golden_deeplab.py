@@ -18,6 +18,73 @@ sys.path.insert(0, HERE)
 import make_golden as MG  # noqa: E402
 
 
+FULL = ("backbone.conv1.weight", "backbone.layer1.0.conv1.weight", "backbone.layer4.2.conv2.weight",
+        "classifier.aspp.convs.4.1.weight", "classifier.aspp.project.0.weight", "classifier.classifier.0.weight",
+        "classifier.classifier.3.bias", "classifier.project.0.weight", "backbone.layer3.22.bn3.weight")
+
+
+def train_step(mods, modeling, state, dtype, plan):
+    """One supcon_pixelcontrast_focal step of the reference DeepLabV3+ in ``dtype``; float64 = the anchor run (same
+    conventions as make_golden.ref_train_step: unmodified modules, pixel loss = _contrastive on the rows the float32
+    run's sampler drew; F.dropout draws the same keep mask from the CPU generator in both precisions)."""
+    from oracle import swiftnet_oracle as O
+    dev = torch.device("cpu")
+    opts = MG.make_opts("supcon_pixelcontrast_focal")
+    opts.deeplab = True
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = modeling.deeplabv3plus_resnet101(opts, num_classes=19, output_stride=16, pretrained_backbone=False)
+    model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
+    assert list(model.state_dict().keys()) == list(state.keys())
+    model = model.to(dtype)
+    model.train()
+    b, h, w = 2, 128, 256
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=51, two_crops=True, cell=32)
+    img, ldw = img.to(dtype), ldw.to(dtype)
+    crit = mods.loss.BoundaryAwareFocalLoss(gamma=0.5, num_classes=19, ignore_id=255, weight=cw, device=dev, opts=opts)
+    supc = mods.loss.SupConLoss(temperature=0.07, contrast_mode="all", base_temperature=0.07, weight=cw, device=dev, opts=opts)
+    proj = O.make_proj(seed=9, dim_in=2048)
+    with torch.no_grad():
+        supc.projection[0].weight.copy_(proj[0]); supc.projection[0].bias.copy_(proj[1])
+        supc.projection[2].weight.copy_(proj[2]); supc.projection[2].bias.copy_(proj[3])
+    supc = supc.to(dtype)
+    pixc = mods.loss.PixelContrastLoss(device=dev)
+    labels = labels.clone()
+    torch.manual_seed(321)
+    seg, before, fine_feat, fine_feat0 = model(img, return_supcon_feature=True)
+    sup = supc(fine_feat, class_labels=weather, mask=None)
+    captured = {}
+    pix = MG.pixel_loss(pixc, fine_feat0, labels, before, captured, plan)
+    segl = crit(seg, labels, {"label_distance_weight": ldw})
+    total = 1 / b * (sup + pix) + segl * 1.2
+    total.backward()
+    np_ = MG.np_
+    f32 = lambda t: np_(t).astype(np.float32)
+    res = dict(total=np_(total).reshape(()), supcon=np_(sup).reshape(()), pixel=np_(pix).reshape(()), seg=np_(segl).reshape(()))
+    res["before"] = f32(before)
+    res["fine_feat_sub"] = f32(fine_feat[:, ::8])
+    res["fine_feat0_sub"] = f32(fine_feat0[:, ::16, ::2, ::2])
+    res["seg_argmax"] = np_(seg.argmax(1)).astype(np.uint8)
+    top2 = seg.detach().topk(2, dim=1)[0]
+    res["seg_margin"] = np_(top2[:, 0] - top2[:, 1]).astype(np.float16)
+    res["seg_logits_sub"] = f32(seg[:, :, ::4, ::4])
+    names = [k for k, _ in model.named_parameters()]
+    grads = {k: p.grad for k, p in model.named_parameters()}
+    res["grad_names"] = np.array(names)
+    res["grad_norms"] = np.array([float(grads[k].norm()) if grads[k] is not None else -1.0 for k in names])
+    for k in FULL:
+        g = grads[k]
+        res["grad::" + k] = f32(g if g.numel() < 400000 else g.flatten()[::37])
+    sd = model.state_dict()
+    bn_keys = [k for k in sd if "running_" in k]
+    res["rs_names"] = np.array(bn_keys)
+    res["rs_norms"] = np.array([float(sd[k].double().norm()) for k in bn_keys])
+    res["proj_grad_norms"] = np.array([float(p.grad.norm()) for p in supc.projection.parameters()])
+    if "pix" in captured:
+        res["anchor_pix"] = np_(captured["pix"]).astype(np.int32); res["anchor_img"] = np_(captured["img"]).astype(np.int32)
+        plan = (captured["img"], captured["pix"], captured["y_"])
+    return res, plan, model
+
+
 def main():
     from oracle import deeplab_oracle as D
     from oracle import swiftnet_oracle as O
@@ -25,65 +92,35 @@ def main():
     mods = MG.import_reference()
     modeling = importlib.import_module("network.modeling")
     torch.set_num_threads(8)
-    dev = torch.device("cpu")
-    opts = MG.make_opts("supcon_pixelcontrast_focal")
-    opts.deeplab = True
     state = D.make_state(seed=7)
-    with contextlib.redirect_stdout(io.StringIO()):
-        model = modeling.deeplabv3plus_resnet101(opts, num_classes=19, output_stride=16, pretrained_backbone=False)
-    missing, unexpected = model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
-    assert list(model.state_dict().keys()) == list(state.keys())
-    model.train()
-    b, h, w = 2, 128, 256
-    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=51, two_crops=True, cell=32)
-    crit = mods.loss.BoundaryAwareFocalLoss(gamma=0.5, num_classes=19, ignore_id=255, weight=cw, device=dev, opts=opts)
-    supc = mods.loss.SupConLoss(temperature=0.07, contrast_mode="all", base_temperature=0.07, weight=cw, device=dev, opts=opts)
-    proj = O.make_proj(seed=9, dim_in=2048)
-    with torch.no_grad():
-        supc.projection[0].weight.copy_(proj[0]); supc.projection[0].bias.copy_(proj[1])
-        supc.projection[2].weight.copy_(proj[2]); supc.projection[2].bias.copy_(proj[3])
-    pixc = mods.loss.PixelContrastLoss(device=dev)
-    labels = labels.clone()
-    torch.manual_seed(321)
-    seg, before, fine_feat, fine_feat0 = model(img, return_supcon_feature=True)
-    sup = supc(fine_feat, class_labels=weather, mask=None)
-    with contextlib.redirect_stdout(io.StringIO()):
-        pix = pixc(fine_feat0, labels=labels, predict=before)
-    segl = crit(seg, labels, {"label_distance_weight": ldw})
-    total = 1 / b * (sup + pix) + segl * 1.2
-    total.backward()
-    np_ = MG.np_
-    res = dict(total=np_(total).reshape(()), supcon=np_(sup).reshape(()), pixel=np_(pix).reshape(()), seg=np_(segl).reshape(()))
-    res["before"] = np_(before)
-    res["fine_feat_sub"] = np_(fine_feat[:, ::8])
-    res["fine_feat0_sub"] = np_(fine_feat0[:, ::16, ::2, ::2])
-    res["seg_argmax"] = np_(seg.argmax(1)).astype(np.uint8)
-    res["seg_logits_sub"] = np_(seg[:, :, ::4, ::4])
-    names = [k for k, _ in model.named_parameters()]
-    grads = {k: p.grad for k, p in model.named_parameters()}
-    res["grad_names"] = np.array(names)
-    res["grad_norms"] = np.array([float(grads[k].norm()) if grads[k] is not None else -1.0 for k in names])
-    for k in ("backbone.conv1.weight", "backbone.layer1.0.conv1.weight", "backbone.layer4.2.conv2.weight",
-              "classifier.aspp.convs.4.1.weight", "classifier.aspp.project.0.weight", "classifier.classifier.0.weight",
-              "classifier.classifier.3.bias", "classifier.project.0.weight", "backbone.layer3.22.bn3.weight"):
-        g = grads[k]
-        res["grad::" + k] = np_(g if g.numel() < 400000 else g.flatten()[::37])
-    sd = model.state_dict()
-    bn_keys = [k for k in sd if "running_" in k]
-    res["rs_names"] = np.array(bn_keys)
-    res["rs_norms"] = np.array([float(sd[k].double().norm()) for k in bn_keys])
-    res["proj_grad_norms"] = np.array([float(p.grad.norm()) for p in supc.projection.parameters()])
+    res, plan, model = train_step(mods, modeling, state, torch.float32, None)
     np.savez_compressed(os.path.join(HERE, "deeplab_step_b2_128x256.npz"), **res)
-    print("deeplab", {k: float(res[k]) for k in ("total", "supcon", "pixel", "seg")})
+    print("deeplab", {k: float(res[k]) for k in ("total", "supcon", "pixel", "seg")}, flush=True)
+    r64, _, _ = train_step(mods, modeling, state, torch.float64, plan)
+    np.savez_compressed(os.path.join(HERE, "deeplab_step_b2_128x256.f64.npz"),
+                        **{k: v for k, v in r64.items() if k not in ("grad_names", "rs_names")})
+    n32, n64 = res["grad_norms"], r64["grad_norms"]
+    print("deeplab fp32-vs-fp64 of the reference:",
+          dict(loss=max(abs(float(res[k]) - float(r64[k])) / abs(float(r64[k])) for k in ("total", "supcon", "pixel", "seg")),
+               logits=float(np.abs(res["before"].astype(np.float64) - r64["before"]).max() / np.abs(r64["before"]).max()),
+               argmax=int((res["seg_argmax"] != r64["seg_argmax"]).sum()),
+               gradnorm_max=float((np.abs(n32 - n64) / n64)[n64 > 0].max())), flush=True)
+    np_ = MG.np_
+    f32 = lambda t: np_(t).astype(np.float32)
     # eval forward at an odd size (fresh state: the training forward above updated the running statistics)
-    model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
-    model.eval()
     img2 = O.synthetic_batch(1, 104, 168, seed=52)[0]
-    with torch.no_grad():
-        seg, before, ff, ff0 = model(img2)
-    np.savez_compressed(os.path.join(HERE, "deeplab_eval_b1_104x168.npz"), before=np_(before),
-                        fine_feat_sub=np_(ff[:, ::8]), fine_feat0_sub=np_(ff0[:, ::16]),
-                        seg_argmax=np_(seg.argmax(1)).astype(np.uint8))
+    for dt, suffix in ((torch.float32, ""), (torch.float64, ".f64")):
+        model = model.to(torch.float32)
+        model.load_state_dict({k: v.clone() for k, v in state.items()}, strict=True)
+        model = model.to(dt)
+        model.eval()
+        with torch.no_grad():
+            seg, before, ff, ff0 = model(img2.to(dt))
+        top2 = seg.topk(2, dim=1)[0]
+        np.savez_compressed(os.path.join(HERE, "deeplab_eval_b1_104x168%s.npz" % suffix), before=f32(before),
+                            fine_feat_sub=f32(ff[:, ::8]), fine_feat0_sub=f32(ff0[:, ::16]),
+                            seg_argmax=np_(seg.argmax(1)).astype(np.uint8),
+                            seg_margin=np_(top2[:, 0] - top2[:, 1]).astype(np.float16))
     print("deeplab eval", tuple(seg.shape), tuple(ff.shape), tuple(ff0.shape))
 
 

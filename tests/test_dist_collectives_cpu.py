@@ -1,5 +1,6 @@
 """CPU: the two exchange primitives of the data-parallel step (dcs_amd/dist.py) on FOUR gloo ranks with ragged anchor
-counts (including a rank that sampled nothing): the gathered set is the rank-ordered concatenation on every rank, and
+counts (including a rank that sampled nothing): the fixed-shape gathered buffer holds every rank's rows at its slot with
+label -1 padding behind them (no count exchange, no host synchronisation), and
 the globally normalised segmentation loss equals the single-process value."""
 import os
 import socket
@@ -12,6 +13,7 @@ import torch.multiprocessing as mp
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 COUNTS = [5, 0, 17, 3]
+CAP = 20
 
 
 def rows_of(rank):
@@ -32,9 +34,9 @@ def worker(rank, world, port, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from dcs_amd.dist import RowGather, SegLossReduce
     X, y = rows_of(rank)
-    Xa, ya, start = RowGather()(X, y)
+    buf, start = RowGather()(X, y, CAP)
     red = SegLossReduce()(seg_of(rank))
-    q.put((rank, Xa, ya, start, red))
+    q.put((rank, buf, start, red))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -51,8 +53,8 @@ def test_four_rank_ragged_gather_and_loss_reduce():
         p.start()
     got = {}
     for _ in range(world):
-        r, Xa, ya, start, red = q.get(timeout=120)
-        got[r] = (Xa.clone(), ya.clone(), start, red.clone())
+        r, buf, start, red = q.get(timeout=120)
+        got[r] = (buf.clone(), start, red.clone())
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -62,7 +64,13 @@ def test_four_rank_ragged_gather_and_loss_reduce():
     n_g = float(segs[:, 1].sum())
     loss_g = float((segs[:, 0] * segs[:, 1]).sum()) / n_g
     for r in range(world):
-        Xa, ya, start, red = got[r]
-        assert torch.equal(Xa, X_all) and torch.equal(ya, y_all)
-        assert start == sum(COUNTS[:r])
+        buf, start, red = got[r]
+        # fixed shape: world x CAP rows of C + 4 floats, rank q's rows at [q * CAP, q * CAP + COUNTS[q]), label -1 beyond
+        assert tuple(buf.shape) == (world * CAP, 8 + 4) and start == r * CAP
+        valid = buf[:, 8] >= 0
+        assert torch.equal(buf[valid][:, :8], X_all) and torch.equal(buf[valid][:, 8], y_all)
+        for q_ in range(world):
+            blk = buf[q_ * CAP:(q_ + 1) * CAP]
+            assert bool((blk[:COUNTS[q_], 8] >= 0).all()) and bool((blk[COUNTS[q_]:, 8] == -1).all())
+            assert float(blk[COUNTS[q_]:, :8].abs().max()) == 0.0 if COUNTS[q_] < CAP else True
         assert abs(float(red[0]) - loss_g) < 1e-6 and float(red[1]) == n_g and abs(float(red[2]) - 1.0 / n_g) < 1e-9

@@ -331,21 +331,82 @@ def test_gather_scatter_rows(ops):
     close(gfd, ref, 1e-7, "scatter")
 
 
-@pytest.mark.parametrize("A,mode", [(8, 1), (64, 1), (76, 0), (304, 0), (608, 0), (33, 0),
-                                    (1216, 0), (2437, 0)])      # > 1024 anchors (gathered global batch): split-row backward GEMM
-def test_contrast_fwd_bwd(ops, A, mode):
-    g = np.random.default_rng(47 + A)
-    X = rnd(A, 128, seed=48 + A) * 0.7
+def _contrast_case(A, mode, C=128, seed=0):
+    g = np.random.default_rng(47 + A + seed)
+    X = rnd(A, C, seed=48 + A + seed) * (0.7 if C == 128 else 0.2)
     if mode == 0:
         T = A // 2
         y = torch.from_numpy(np.tile(g.integers(0, 6, size=T), 2).astype(np.float32)) if A % 2 == 0 else \
             torch.from_numpy(g.integers(0, 3, size=A).astype(np.float32))
     else:
         y = torch.from_numpy(np.tile(g.integers(0, 3, size=A // 2), 2).astype(np.float32))
+    return X, y
+
+
+@pytest.mark.parametrize("A,mode", [(8, 1), (64, 1), (76, 0), (304, 0), (608, 0), (33, 0), (1000, 0), (256, 1),
+                                    (1216, 0), (2437, 0), (4864, 0), (1280, 1)])   # > 1024: the symmetric strip kernels
+def test_contrast_fwd_bwd(ops, A, mode):
+    """Fused similarity / InfoNCE kernels (dcs_contrast_fused) against the float64 autograd statement of
+    utils/loss.py:339-389 / :175-204.  A <= 1024: strip-resident family; larger: symmetric tile sweeps."""
+    X, y = _contrast_case(A, mode)
     loss_r, dX_r = E.contrast_fwd_bwd(X.double(), y.double(), mode)
     loss, dX = ops.contrast_fwd_bwd(X.to(DEV), y.to(DEV), mode)
     close(loss, loss_r, 2e-5, "loss")
     close(dX, dX_r, 2e-4, "dX")
+    loss2, dX2 = ops.contrast_fwd_bwd(X.to(DEV), y.to(DEV), mode)          # deterministic (no float atomics)
+    assert torch.equal(loss, loss2) and torch.equal(dX, dX2)
+
+
+@pytest.mark.parametrize("A,cap,world,mode", [(37, 64, 2, 0), (300, 608, 2, 0), (10, 16, 4, 1), (500, 608, 4, 0)])
+def test_contrast_padded_strided_gather_buffer(ops, A, cap, world, mode):
+    """The data-parallel layout: [world * cap] rows of 132 floats (128 channels, label, 3 pad), label -1 on the rows a
+    rank did not fill.  Padding rows must take part in nothing: loss and gradient equal the compact problem's, and the
+    padding rows' gradient is exactly zero."""
+    g = np.random.default_rng(5 + A)
+    counts = [A] + [int(v) for v in g.integers(0 if mode == 0 else 2, cap + 1, size=world - 1)]
+    if mode == 1:
+        counts = [c - c % 2 for c in counts]
+    buf = torch.zeros(world * cap, 132)
+    buf[:, 128] = -1.0
+    Xs, ys = [], []
+    for r, c in enumerate(counts):
+        Xr, yr = _contrast_case(max(c, 2), mode, seed=r)
+        Xr, yr = Xr[:c], yr[:c]
+        buf[r * cap:r * cap + c, :128] = Xr
+        buf[r * cap:r * cap + c, 128] = yr
+        Xs.append(Xr); ys.append(yr)
+    Xc, yc = torch.cat(Xs), torch.cat(ys)
+    loss_r, dX_r = E.contrast_fwd_bwd(Xc.double(), yc.double(), mode)
+    bd = buf.to(DEV)
+    loss, dX = ops.contrast_fwd_bwd(bd[:, :128], bd[:, 128], mode)
+    close(loss, loss_r, 2e-5, "loss")
+    dX = dX.cpu()
+    valid = buf[:, 128] >= 0
+    close(dX[valid], dX_r, 2e-4, "dX of the valid rows")
+    assert float(dX[~valid].abs().max()) == 0.0 if bool((~valid).any()) else True
+    # and the dense emulation of the padded problem agrees with itself
+    loss_p, dX_p = E.contrast_fwd_bwd(buf[:, :128].double(), buf[:, 128].double(), mode)
+    close(loss_p, loss_r, 1e-12, "emulation, padded vs compact")
+
+
+def test_contrast_explicit_mask_and_wide_features(ops):
+    """SupConLoss(mask=...) (utils/loss.py:148-159: an explicit, possibly asymmetric [bsz,bsz] mask) and the 2048-channel
+    rows of DeepLab's pixel contrast (the kernel returns G + G^T, one GEMM finishes dX)."""
+    g = np.random.default_rng(3)
+    b = 12
+    X = rnd(2 * b, 128, seed=91) * 0.7
+    mask = torch.from_numpy((g.random((b, b)) < 0.4).astype(np.float32))
+    mask[torch.arange(b), (torch.arange(b) + 1) % b] = 1.0            # every row keeps a positive
+    y = torch.arange(b, dtype=torch.float32).repeat(2)
+    loss_r, dX_r = E.contrast_fwd_bwd(X.double(), y.double(), 1, mask=mask.double())
+    loss, dX = ops.contrast_fwd_bwd(X.to(DEV), y.to(DEV), 1, mask=mask.to(DEV))
+    close(loss, loss_r, 2e-5, "masked supcon loss")
+    close(dX, dX_r, 2e-4, "masked supcon dX")
+    Xw, yw = _contrast_case(152, 0, C=2048)
+    loss_r, dX_r = E.contrast_fwd_bwd(Xw.double(), yw.double(), 0)
+    loss, dX = ops.contrast_fwd_bwd(Xw.to(DEV), yw.to(DEV), 0)
+    close(loss, loss_r, 2e-5, "wide loss")
+    close(dX, dX_r, 2e-4, "wide dX")
 
 
 def test_adam_and_small_helpers(ops):

@@ -2,9 +2,12 @@
   * the golden vectors produced by the reference (tests/golden/*.npz), and
   * the CPU oracle on other seeded inputs (odd sizes, every criterion),
 plus size-independent properties at a larger size (finite losses, loss decreases under training).
-Tolerance (north star): losses / logits / features within 1e-3 relative to the tensor's max in fp32; class-id
-argmax equal except at numerical near-ties (checked against the logit gap); gradients 1e-2 relative L2 (the
-resolution of fp32 gradients on these fixtures, see tests/test_host_logic_cpu.py)."""
+Tolerance (north star): losses / logits / features within 1e-3 relative to the tensor's max in fp32; class-id argmax
+identical (mismatch counts are recorded; a differing pixel must be one the reference itself cannot decide in fp32).
+Gradients, gradient norms and BatchNorm buffers have no tolerance constant: they are held to K = 2 x the reference's
+OWN float32-vs-float64 error on the same fixture (tests/budget.py; float64 anchors from tests/golden/make_golden.py),
+with split-K launches on and off.  One well-conditioned fixture (B=8 at 1024x2048: >= 1024 samples per channel in
+every BatchNorm) is additionally held to 1e-2 absolute."""
 import os
 
 import numpy as np
@@ -12,7 +15,8 @@ import pytest
 import torch
 
 from oracle import swiftnet_oracle as O
-from step_check import check_argmax, close, close_l2, run_and_check_step
+from budget import Budget, rel_l2, rel_max
+from step_check import check_argmax, close, close_l2, load_anchor, run_and_check_step
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -50,9 +54,33 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("ksplit", ["1", "0"])
 @pytest.mark.parametrize("fname,criterion,shape,rng_seed", CASES)
-def test_train_step_matches_reference_golden(golden_dir, fname, criterion, shape, rng_seed):
-    run_and_check_step(build(criterion), load(golden_dir, fname), criterion, shape, rng_seed, rtol=RTOL, grad_rtol=1e-2)
+def test_train_step_matches_reference_golden(golden_dir, monkeypatch, fname, criterion, shape, rng_seed, ksplit):
+    monkeypatch.setenv("DCS_KSPLIT", ksplit)                 # split-K launches on (default) and off
+    run_and_check_step(build(criterion), load(golden_dir, fname), criterion, shape, rng_seed, rtol=RTOL,
+                       g64=load_anchor(golden_dir, fname), name=f"gpu_{fname[:-4]}_ksplit{ksplit}")
+
+
+def test_train_step_well_conditioned_fixture(golden_dir):
+    """B=8 at 1024x2048 (8 x 8 x 16 = 1024 samples per channel in the coarsest BatchNorm): besides the K x reference
+    budget, every stored gradient tensor is within 1e-2 (relative L2) and every gradient norm within 1e-2 of the
+    float64 anchor -- an absolute bar that does not lean on the fixture's conditioning."""
+    fname = "step_pixel_focal_b8_1024x2048.npz"
+    g, g64 = load(golden_dir, fname), load_anchor(golden_dir, fname)
+    ts = build("pixelcontrast_focal", batch_size=8)
+    shape = dict(b=8, h=1024, w=2048, seed=14, two=False, cell=64)
+    run_and_check_step(ts, g, "pixelcontrast_focal", shape, 5, rtol=RTOL, g64=g64, name="gpu_" + fname[:-4],
+                       argmax_stride=4)
+    params = dict(ts.model.named_parameters())
+    bud = Budget("gpu_well_conditioned_abs")
+    for key in g.files:
+        if key.startswith("grad::"):
+            bud.check_abs(key, rel_l2(params[key[6:]].grad, g64[key]), 1e-2)
+    for k, n64 in zip([str(x) for x in g["grad_names"]], g64["grad_norms"]):
+        if n64 > 0:
+            bud.check_abs("|grad| " + k, abs(float(params[k].grad.double().norm()) - n64) / n64, 1e-2)
+    bud.finish()
 
 
 def test_eval_forward_matches_reference_golden(golden_dir):
@@ -65,42 +93,74 @@ def test_eval_forward_matches_reference_golden(golden_dir):
     close(before, g["before"], RTOL, "before")
     close(ff, g["fine_feat"], RTOL, "fine_feat")
     close(seg[:, :, ::4, ::4], g["seg_logits_sub"], RTOL, "seg")
-    check_argmax(seg, g["seg_argmax"], RTOL)
+    from step_check import argmax_vs_anchor
+    bud = Budget("gpu_eval_fwd_b1_120x200")
+    g64 = load_anchor(golden_dir, "eval_fwd_b1_120x200.npz")
+    bud.note("output before", err_hip=rel_max(before, g64["before"]), err_ref32=rel_max(g["before"], g64["before"]))
+    argmax_vs_anchor(bud, seg, g, g64, expect_exact=True)        # class ids bit-exact on this fixture
+    bud.finish()
     assert seg.is_contiguous() and tuple(seg.shape) == (1, 19, 120, 200)
 
 
+def _oracle_step(dt, criterion, b, img, labels, ldw, weather, cw, seed, mkldnn=True):
+    state = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in O.make_state(seed=1).items()}
+    proj = [p.to(dt) for p in O.make_proj(seed=2)]
+    torch.manual_seed(seed)
+    with torch.backends.mkldnn.flags(enabled=mkldnn):
+        ref, grads, gproj = O.train_step(state, proj, None, img.to(dt), labels.clone(), ldw.to(dt), weather, cw.to(dt),
+                                         criterion, b)
+    return ref, grads, state
+
+
+@pytest.mark.parametrize("ksplit", ["1", "0"])
 @pytest.mark.parametrize("criterion,two,b,h,w", [
     ("supcon_focal", True, 2, 224, 352), ("supcon_simclr_pixelcontrast_focal", True, 2, 256, 288),
     ("supcon_crossentropy", True, 2, 200, 320), ("focal", False, 3, 232, 416), ("supcon_simclr_cross_entropy", True, 2, 256, 384)])
-def test_train_step_matches_oracle(criterion, two, b, h, w):
+def test_train_step_matches_oracle(monkeypatch, criterion, two, b, h, w, ksplit):
+    """Criteria without a reference golden: the oracle (pinned to the reference by the goldens) is evaluated here in
+    float32 AND float64; the HIP step is held to K x the oracle's own fp32-vs-fp64 error, split-K on and off."""
+    monkeypatch.setenv("DCS_KSPLIT", ksplit)
     img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=70 + b, two_crops=two, cell=32)
     ts = build(criterion, batch_size=b, cw=cw)
     s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
     torch.manual_seed(9)
     out = ts.step((s0, dict(left=img[b:])) if two else s0, do_optimizer_step=False)
-    state, proj = O.make_state(seed=1), O.make_proj(seed=2)
-    torch.manual_seed(9)
-    ref, grads, gproj = O.train_step(state, proj, None, img, labels.clone(), ldw, weather, cw, criterion, b)
+    ref, grads, state = _oracle_step(torch.float32, criterion, b, img, labels, ldw, weather, cw, 9)
+    r64, g64, _ = _oracle_step(torch.float64, criterion, b, img, labels, ldw, weather, cw, 9)
+    # a second float32 execution path of the same oracle (ATen's native convolution instead of oneDNN): one fp32 run
+    # is a single draw of the rounding error; the budget unit is the larger of the two (tests/budget.py)
+    ref_b, grads_b, _ = _oracle_step(torch.float32, criterion, b, img, labels, ldw, weather, cw, 9, mkldnn=False)
+    if "anchors" in ref:                                   # the float64 anchor must be the same function
+        assert all(torch.equal(a, c) for a, c in zip(ref["anchors"], r64["anchors"])), "fixture samples differently in fp64"
+        if not all(torch.equal(a, c) for a, c in zip(ref["anchors"], ref_b["anchors"])):
+            grads_b = grads                                # near-tie in the second path's argmax: other anchors, unusable
     close(out["total"].reshape(()), ref["total"], RTOL, "total")
     close(out["fine_feat"], ref["fine_feat"], RTOL, "fine_feat")
     close(out["left_seg"], ref["seg_logits"], RTOL, "seg")
-    check_argmax(out["left_seg"], ref["seg_logits"].argmax(1).numpy().astype(np.uint8), RTOL)
+    bud = Budget(f"gpu_oracle_{criterion}_{h}x{w}_ksplit{ksplit}")
+    n_bad = check_argmax(out["left_seg"], ref["seg_logits"].argmax(1).numpy().astype(np.uint8), RTOL)
+    bud.note("argmax", mismatches_hip_vs_oracle32=n_bad,
+             mismatches_oracle32_vs_oracle64=int((ref["seg_logits"].argmax(1) != r64["seg_logits"].argmax(1)).sum()))
+    bud.note("output seg_logits", err_hip=rel_max(out["left_seg"], r64["seg_logits"]),
+             err_ref32=rel_max(ref["seg_logits"], r64["seg_logits"]))
     params = dict(ts.model.named_parameters())
+    live = [k for k, gr in grads.items() if gr is not None]
+    nerr = lambda gd, k: abs(float(gd[k].double().norm()) - float(g64[k].norm())) / float(g64[k].norm())
+    worst_n = max(max(nerr(grads, k), nerr(grads_b, k)) for k in live)     # see step_check.run_and_check_step: norms are single numbers
     for k, gref in grads.items():
         if gref is None:
             assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
-        else:
-            # fp32 gradient resolution at these small sizes (BatchNorm over <= 300 samples in layer4): two equally valid
-            # fp32 summation orders of the same kernels (split-K on / off, outputs equal to 2e-6) measure 0.7e-2 and
-            # 2.9e-2 against the float64 oracle on the 200x320 case; exactness of the graph is pinned in float64 by
-            # tests/test_host_logic_cpu.py
-            close_l2(params[k].grad, gref.numpy(), 4e-2, k)
+            continue
+        bud.check("grad " + k, params[k].grad, gref, g64[k], metric=rel_l2, floor=1e-5, e32=rel_l2(grads_b[k], g64[k]))
+        bud.check("|grad| " + k, float(params[k].grad.double().norm()), float(gref.double().norm()), float(g64[k].norm()),
+                  metric=rel_max, floor=worst_n)
     sd = ts.model.state_dict()
     for k, v in state.items():
         if "running_" in k:
             close(sd[k], v.numpy(), RTOL, k)
         if "num_batches" in k:
             assert int(sd[k]) == int(v), k
+    bud.finish()
 
 
 def test_loss_units_match_reference_golden(golden_dir):
