@@ -74,6 +74,174 @@ void seg_loss_kernel(const float* __restrict__ logits, int64_t* __restrict__ tar
   if (threadIdx.x == 0) { partial[2 * blockIdx.x] = (float)sl[0]; partial[2 * blockIdx.x + 1] = (float)sc[0]; }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused logits upsampling + log-softmax + focal / cross-entropy loss + gradient (network/utils.py:8 `upsample`,
+// utils/loss.py:41-42, :60-73): the full-resolution logits [N,C,H,W] (2.55 GB at C3) and their gradient are never
+// materialised.  Input = the low-resolution NHWC logits [N,ih,iw,cs]; output = d(sum loss)/d(low-res logits) in the
+// same layout, i.e. the adjoint of the bilinear upsampling applied on the fly.  H = F*ih, W = F*iw, F in {2, 4}.
+//
+// Block = one tile of TH x TW = 8 x 32 low-resolution pixels of one image.
+//   stage: the tile's logits + a 1-pixel halo -> LDS.
+//   phase A, one output pixel at a time over the tile's F*TH x F*TW owned pixels and the F/2-pixel ring around them
+//     (pixels whose bilinear taps touch the tile): interpolate the C logits (lin_src: the very weights of
+//     upsample_to_nchw_kernel), log-sum-exp, loss coefficient -> LDS (lse, coef, target: 9 bytes per pixel); owned
+//     pixels add to the loss / count and get the in-place 255 -> 0 label rewrite (utils/loss.py:43).
+//   phase B, one thread per low-resolution pixel: GATHER its gradient from the <= (2F)^2 output pixels of its footprint
+//     (p_c re-evaluated from the staged logits: 4x redundant exp work, ~0.1 ms at C3, in exchange for a fixed summation
+//     order: no float atomics, bitwise reproducible).
+constexpr int SLF_TH = 8, SLF_TW = 32;
+
+template <int F, int MAXC>
+__global__ __launch_bounds__(256)
+void seg_loss_fused_kernel(const float* __restrict__ lr, const int cs, int64_t* __restrict__ target,
+                           const float* __restrict__ ldw, const float* __restrict__ cw, float* __restrict__ glr,
+                           float* __restrict__ partial, const int C, const int ih, const int iw, const int mode,
+                           const float gamma, const int ignore, const int tiles_x, const int tiles_y) {
+  constexpr int LH = SLF_TH + 2, LW = SLF_TW + 2;                 // staged low-res rows / cols (1-pixel halo)
+  constexpr int RH = F * SLF_TH + F, RW = F * SLF_TW + F;         // phase-A region (owned + F/2 ring)
+  constexpr int LP = MAXC + 1;                                    // odd pixel stride in LDS: conflict-free tap reads
+  __shared__ float tile[LH * LW * LP];
+  __shared__ float s_lse[RH * RW], s_coef[RH * RW];
+  __shared__ signed char s_t[RH * RW];
+  __shared__ double s_red[2][4];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int tx = b % tiles_x; b /= tiles_x;
+  const int ty = b % tiles_y;
+  const int n = b / tiles_y;
+  const int iy0 = ty * SLF_TH, ix0 = tx * SLF_TW;
+  const int H = F * ih, W = F * iw;
+  const float sc = 1.f / (float)F;                                // = ih / H: the scale lin_src expects
+  // ---- stage the low-res tile (rows iy0-1 .. iy0+TH, clamped reads; clamped duplicates are never used with weight)
+  for (int e = tid; e < LH * LW; e += 256) {
+    const int ly = e / LW, lx = e - ly * LW;
+    int gy = iy0 - 1 + ly, gx = ix0 - 1 + lx;
+    gy = gy < 0 ? 0 : (gy > ih - 1 ? ih - 1 : gy);
+    gx = gx < 0 ? 0 : (gx > iw - 1 ? iw - 1 : gx);
+    const float* src = lr + (((long long)n * ih + gy) * iw + gx) * cs;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) tile[e * LP + c] = c < C ? src[c] : 0.f;
+  }
+  __syncthreads();
+  // ---- phase A
+  const int oy0 = F * iy0 - F / 2, ox0 = F * ix0 - F / 2;         // region origin (may be negative)
+  double lsum = 0.0, lcnt = 0.0;
+  for (int e = tid; e < RH * RW; e += 256) {
+    const int ry = e / RW, rx = e - ry * RW;
+    const int oy = oy0 + ry, ox = ox0 + rx;
+    float lse = 0.f, coef = 0.f;
+    int tt = 0;
+    if (oy >= 0 && oy < H && ox >= 0 && ox < W) {
+      const Lin ly = lin_src(oy, sc, ih), lx = lin_src(ox, sc, iw);
+      const float* p00 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
+      const float* p01 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
+      const float* p10 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
+      const float* p11 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
+      const long long pix = ((long long)n * H + oy) * W + ox;
+      long long t = target[pix];
+      const bool owned = ry >= F / 2 && ry < F / 2 + F * SLF_TH && rx >= F / 2 && rx < F / 2 + F * SLF_TW;
+      bool counted;
+      float a = 1.f;
+      if (mode == 4) {
+        counted = t != ignore;
+        if (!counted || t < 0 || t >= C) t = 0;
+      } else {
+        if (t == ignore) { t = 0; if (owned) target[pix] = 0; }    // utils/loss.py:43 (in place)
+        if (t < 0 || t >= C) t = 0;
+        a = ldw[pix];
+        counted = a > 0.f;
+      }
+      float v[MAXC], mx = -INFINITY, xt = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        if (c < C) {
+          // same association as upsample_to_nchw_kernel: x first, then y
+          const float top = fmaf(lx.w1, p01[c], lx.w0 * p00[c]);
+          const float bot = fmaf(lx.w1, p11[c], lx.w0 * p10[c]);
+          v[c] = fmaf(ly.w1, bot, ly.w0 * top);
+        } else v[c] = -INFINITY;
+        mx = fmaxf(mx, v[c]);
+        if (c == (int)t) xt = v[c];
+      }
+      float se = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) se += c < C ? expf(v[c] - mx) : 0.f;
+      lse = mx + logf(se);
+      const float logpt = xt - lse;
+      if (mode == 4) coef = counted ? 1.f : 0.f;
+      else {
+        const float pt = expf(logpt);
+        const float mod = expf(gamma * (1.f - pt));
+        const float w = cw ? cw[t] : 1.f;
+        coef = mode == 0 ? w * a * mod : (mode == 1 ? mod : (mode == 2 ? a * mod : w * mod));
+      }
+      if (owned) { lsum += (double)(-coef * logpt); lcnt += counted ? 1.0 : 0.0; }
+      tt = (int)t;
+    }
+    s_lse[e] = lse; s_coef[e] = coef; s_t[e] = (signed char)tt;
+  }
+  __syncthreads();
+  // ---- phase B: thread = low-res pixel (ly_, lx_) of the tile
+  {
+    const int ly_ = tid / SLF_TW, lx_ = tid - ly_ * SLF_TW;
+    const int iy = iy0 + ly_, ix = ix0 + lx_;
+    if (iy < ih && ix < iw) {
+      float acc[MAXC];
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
+      // footprint: outputs whose taps include this pixel: [F*i - F/2 - (F-1)... ] conservatively [F*i - F, F*i + 2F) clipped
+      const int ylo = F * iy - F < 0 ? 0 : F * iy - F, yhi = F * iy + 2 * F - 1 > H - 1 ? H - 1 : F * iy + 2 * F - 1;
+      const int xlo = F * ix - F < 0 ? 0 : F * ix - F, xhi = F * ix + 2 * F - 1 > W - 1 ? W - 1 : F * ix + 2 * F - 1;
+      for (int oy = ylo; oy <= yhi; ++oy) {
+        const Lin ly = lin_src(oy, sc, ih);
+        const float wy = (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
+        if (wy == 0.f) continue;
+        const int ry = oy - oy0;
+        if (ry < 0 || ry >= RH) continue;                          // cannot happen for wy != 0; keeps LDS reads in range
+        for (int ox = xlo; ox <= xhi; ++ox) {
+          const Lin lx = lin_src(ox, sc, iw);
+          const float wx = (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
+          if (wx == 0.f) continue;
+          const int rx = ox - ox0;
+          if (rx < 0 || rx >= RW) continue;
+          const int e = ry * RW + rx;
+          const float coef = s_coef[e];
+          if (coef == 0.f) continue;
+          const float lse = s_lse[e];
+          const int t = s_t[e];
+          const float* p00 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
+          const float* p01 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
+          const float* p10 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
+          const float* p11 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
+          const float wc = wy * wx * coef;
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) {
+            if (c < C) {
+              const float top = fmaf(lx.w1, p01[c], lx.w0 * p00[c]);
+              const float bot = fmaf(lx.w1, p11[c], lx.w0 * p10[c]);
+              const float vc = fmaf(ly.w1, bot, ly.w0 * top);
+              // d(-coef logpt)/dv_c = coef (p_c - [c == t])   (pt is detached: loss.py:63)
+              acc[c] = fmaf(wc, expf(vc - lse) - (c == t ? 1.f : 0.f), acc[c]);
+            }
+          }
+        }
+      }
+      float* dst = glr + (((long long)n * ih + iy) * iw + ix) * cs;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) if (c < cs) dst[c] = c < C ? acc[c] : 0.f;
+      for (int c = MAXC; c < cs; ++c) dst[c] = 0.f;
+    }
+  }
+  // ---- block reduction of the loss / count
+  lsum = dcs_wave_sum_d(lsum); lcnt = dcs_wave_sum_d(lcnt);
+  if ((tid & 63) == 0) { s_red[0][tid >> 6] = lsum; s_red[1][tid >> 6] = lcnt; }
+  __syncthreads();
+  if (tid == 0) {
+    partial[2 * blockIdx.x] = (float)((s_red[0][0] + s_red[0][1]) + (s_red[0][2] + s_red[0][3]));
+    partial[2 * blockIdx.x + 1] = (float)((s_red[1][0] + s_red[1][1]) + (s_red[1][2] + s_red[1][3]));
+  }
+}
+
 __global__ void seg_loss_final_kernel(const float* __restrict__ partial, float* __restrict__ out, int blocks) {
   __shared__ double sl[256];
   __shared__ double sc[256];
@@ -423,6 +591,27 @@ extern "C" int dcs_seg_loss(const float* logits, int64_t* target, const float* l
   else
     hipLaunchKernelGGL(seg_loss_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, dcs_stream(stream), logits, target, ldw, cw,
                        grad, partial, N, C, HW, mode, gamma, ignore);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_seg_loss_fused(const float* logits_lr, int cs, int64_t* target, const float* ldw, const float* cw,
+                                  float* grad_lr, float* partial, int N, int C, int ih, int iw, int H, int W, int mode,
+                                  float gamma, int ignore, int blocks, void* stream) {
+  DCS_CHECK_ARG(logits_lr && target && grad_lr && partial && N > 0 && C > 0 && C <= 20 && cs >= C && ih > 0 && iw > 0);
+  DCS_CHECK_ARG(mode >= 0 && mode <= 4 && (mode == 4 || ldw));
+  if (H <= 0 || W <= 0 || H % ih != 0 || W % iw != 0 || H / ih != W / iw) return DCS_E_UNSUPPORTED;
+  const int F = H / ih;
+  const int tiles_x = (iw + SLF_TW - 1) / SLF_TW, tiles_y = (ih + SLF_TH - 1) / SLF_TH;
+  DCS_CHECK_ARG((long long)N * tiles_x * tiles_y == blocks);
+  hipStream_t s = dcs_stream(stream);
+  if (F == 4)
+    hipLaunchKernelGGL((seg_loss_fused_kernel<4, 20>), dim3((unsigned)blocks), dim3(256), 0, s, logits_lr, cs, target, ldw, cw,
+                       grad_lr, partial, C, ih, iw, mode, gamma, ignore, tiles_x, tiles_y);
+  else if (F == 2)
+    hipLaunchKernelGGL((seg_loss_fused_kernel<2, 20>), dim3((unsigned)blocks), dim3(256), 0, s, logits_lr, cs, target, ldw, cw,
+                       grad_lr, partial, C, ih, iw, mode, gamma, ignore, tiles_x, tiles_y);
+  else
+    return DCS_E_UNSUPPORTED;
   DCS_LAUNCH_RET();
 }
 

@@ -139,7 +139,7 @@ class DeepLabEngine:
         return ops.conv_fwd(x, conv.weight, s, p, dil=d, **kw), None
 
     # ------------------------------------------------------------------ forward
-    def forward(self, img, training, supcon, need_grad):
+    def forward(self, img, training, supcon, need_grad, lazy_seg=False):
         bb, hd = self.bb, self.head
         self._nbt = []
         tape = [] if need_grad else None
@@ -217,7 +217,7 @@ class DeepLabEngine:
         bnc = self._bn(yc, cbn, training)
         zc = ops.bn_act(yc, bnc, relu=True)
         before = ops.conv_fwd(zc, c3.weight, 1, 0, bias=c3.bias, dst_cs=LOGIT_CS)
-        seg = ops.upsample_to_nchw(before, self.num_classes, H, W)
+        seg = before.new_zeros(1) if lazy_seg else ops.upsample_to_nchw(before, self.num_classes, H, W)
         if self.lazy_ff0:       # hand out the low-resolution map, rows are interpolated on demand
             ff0 = out[:B] if B != Bm else out.view(out.shape)
         else:
@@ -391,18 +391,20 @@ class DeepLabEngine:
 
 class _DeepLabFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, engine: DeepLabEngine, img, training, supcon, grad_enabled, *params):
+    def forward(ctx, engine: DeepLabEngine, img, training, supcon, grad_enabled, lazy_seg, *params):
         need_grad = grad_enabled and any(p.requires_grad for p in params)
         ctx.set_materialize_grads(False)
-        seg, before, ff, ff0, saved = engine.forward(img, training, supcon, need_grad)
-        ctx.engine, ctx.saved, ctx.params = engine, saved, params
+        seg, before, ff, ff0, saved = engine.forward(img, training, supcon, need_grad, lazy_seg)
+        ctx.engine, ctx.saved, ctx.params, ctx.lazy_seg = engine, saved, params, lazy_seg
+        if lazy_seg:
+            ctx.mark_non_differentiable(seg)
         return seg, before, ff, ff0
 
     @staticmethod
     def backward(ctx, g_seg, g_before, g_ff, g_ff0):
         if ctx.saved is None:
             raise RuntimeError("DeepLab backward without a recorded forward")
-        g_seg = g_seg.contiguous() if g_seg is not None else None
+        g_seg = g_seg.contiguous() if (g_seg is not None and not ctx.lazy_seg) else None
         g_ff = g_ff.contiguous() if g_ff is not None else None
         grads = ctx.engine.backward(ctx.saved, g_seg, g_before, g_ff, g_ff0)
         flat = ctx.engine.flat
@@ -418,7 +420,7 @@ class _DeepLabFn(torch.autograd.Function):
                 res.append(None)
             else:
                 res.append(gp)
-        return (None, None, None, None, None) + tuple(res)
+        return (None, None, None, None, None, None) + tuple(res)
 
 
 class DeepLabV3(nn.Module):
@@ -450,9 +452,14 @@ class DeepLabV3(nn.Module):
     def forward(self, left_img, return_supcon_feature=False):
         for t in (left_img if isinstance(left_img, (list, tuple)) else [left_img]):
             ops.require_device(t, "left_img")
+        lazy = bool(self.training and torch.is_grad_enabled() and getattr(self, "lazy_pred_segmap", True))
         seg, before, ff, ff0 = _DeepLabFn.apply(self._get_engine(), left_img, self.training, bool(return_supcon_feature),
-                                                torch.is_grad_enabled(), *list(self.parameters()))
+                                                torch.is_grad_enabled(), lazy, *list(self.parameters()))
         before_nchw = before[..., :self.num_classes].permute(0, 3, 1, 2)
+        if lazy:
+            from .losses import LazyLogits
+            first = left_img[0] if isinstance(left_img, (list, tuple)) else left_img
+            seg = LazyLogits(before, self.num_classes, first.shape[-2:])
         if self.lazy_fine_feat0:
             from .losses import LazyUpsampled
             return seg, before_nchw, ff.permute(0, 3, 1, 2), LazyUpsampled(ff0.permute(0, 3, 1, 2), before_nchw.shape[-2:])
@@ -462,8 +469,10 @@ class DeepLabV3(nn.Module):
 def _segm_resnet(opts, layers, num_classes, output_stride):
     aspp_dilate = [12, 24, 36] if output_stride == 8 else [6, 12, 18]
     backbone = _resnet_backbone(layers, output_stride)
-    return DeepLabV3(backbone, DeepLabHeadV3Plus(2048, 256, num_classes, aspp_dilate), num_classes,
-                     lazy_fine_feat0=bool(getattr(opts, "lazy_fine_feat0", False)))
+    m = DeepLabV3(backbone, DeepLabHeadV3Plus(2048, 256, num_classes, aspp_dilate), num_classes,
+                  lazy_fine_feat0=bool(getattr(opts, "lazy_fine_feat0", False)))
+    m.lazy_pred_segmap = bool(getattr(opts, "lazy_pred_segmap", True))     # see losses.LazyLogits
+    return m
 
 
 def deeplabv3plus_resnet101(opts, num_classes=21, output_stride=8, pretrained_backbone=True):

@@ -111,6 +111,101 @@ class _UpsampleNCHWFn(torch.autograd.Function):
         return gx.permute(0, 3, 1, 2), None
 
 
+class LazyLogits(torch.Tensor):
+    """``pred_segmap`` = F.interpolate(pred_segmap_beforeup, (H, W), bilinear, align_corners=False) (network/utils.py:8,
+    weathernet.py:93) that is only built if somebody touches it.
+
+    The reference materialises the full-resolution logits [B,19,H,W] (2.55 GB at C3) in the model and the focal / CE
+    loss reads them back, then autograd folds a gradient of the same size.  The training loop hands ``left_seg`` to the
+    criterion and to nothing else (trainer.py:121-201), and the criteria here (BoundaryAwareFocalLoss, FocalLoss2,
+    SemsegCrossEntropy) recognise this handle and run ONE fused kernel on the low-resolution logits instead
+    (dcs_seg_loss_fused): upsampling, log-softmax, loss and the adjoint of the upsampling, nothing full-resolution in
+    HBM.  Everything else -- ``left_seg.detach().max(1)``, slicing, torch's own ``nn.CrossEntropyLoss`` (the reference's
+    ce_criterion, utils/init_trainer.py:223), ``.cpu()`` -- triggers ``__torch_function__``, which materialises the
+    dense tensor once (differentiably: gradients flow back into the low-resolution logits) and carries on with it, so
+    any caller sees an ordinary [B,C,H,W] tensor.  Shape / dtype / device queries do not materialise."""
+
+    @staticmethod
+    def __new__(cls, before_raw, num_classes, size):
+        B = before_raw.shape[0]
+        r = torch.Tensor._make_wrapper_subclass(cls, (B, num_classes, int(size[0]), int(size[1])), dtype=before_raw.dtype,
+                                                device=before_raw.device, requires_grad=False)
+        r._before_raw = before_raw                  # [B,h,w,cs] NHWC, autograd output of the model node
+        r._nc, r._size, r._dense = num_classes, (int(size[0]), int(size[1])), None
+        return r
+
+    _META = None
+
+    def materialize(self):
+        if self._dense is None:
+            v = self._before_raw[..., :self._nc].permute(0, 3, 1, 2)
+            self._dense = _UpsampleNCHWFn.apply(v, self._size)
+        return self._dense
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if cls._META is None:
+            T = torch.Tensor
+            cls._META = {T.shape.__get__, T.dtype.__get__, T.device.__get__, T.size, T.dim, T.ndim.__get__, T.is_cuda.__get__,
+                         T.requires_grad.__get__, T.is_floating_point, T.numel, T.layout.__get__, T.ndimension,
+                         T.grad_fn.__get__, T.is_leaf.__get__, T.element_size}
+        if func in cls._META:
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*args, **kwargs)
+        from torch.utils._pytree import tree_map
+        dense = lambda a: a.materialize() if isinstance(a, LazyLogits) else a
+        with torch._C.DisableTorchFunctionSubclass():
+            return func(*tree_map(dense, args), **tree_map(dense, kwargs))
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        # only reached by callers that bypass __torch_function__ (C++ entry points): same answer, dense tensor
+        from torch.utils._pytree import tree_map
+        dense = lambda a: a.materialize() if isinstance(a, LazyLogits) else a
+        return func(*tree_map(dense, args), **tree_map(dense, kwargs or {}))
+
+    def __repr__(self):
+        return f"LazyLogits(shape={tuple(self._size)}, materialized={self._dense is not None})"
+
+
+class _SegLossFusedFn(torch.autograd.Function):
+    """Loss on a LazyLogits handle: one kernel from the low-resolution NHWC logits to the loss and their gradient."""
+
+    @staticmethod
+    def forward(ctx, before_raw, nc, target, ldw, cw, mode, gamma, ignore, reduce_fn=None):
+        out, grad = ops.seg_loss_fused(before_raw.detach(), nc, target, ldw, cw, mode, gamma, ignore)
+        if reduce_fn is not None:
+            out = reduce_fn(out)
+        ctx.grad, ctx.out = grad, out
+        return out[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        grad = ctx.grad
+        if grad is None:
+            raise RuntimeError("seg loss backward called twice")
+        ctx.grad = None
+        ops.scale_inplace(grad, _scalar(g), ctx.out[2:3])
+        return grad, None, None, None, None, None, None, None, None
+
+
+def _seg_loss(input, target, ldw, cw, mode, gamma, ignore, reduce_fn):
+    """Focal / CE loss of ``input`` = full-resolution logits, low-resolution logits (upsampled first like
+    utils/loss.py:41-42) or a LazyLogits handle (fused: never upsampled in memory)."""
+    target = _prep_target(target)
+    if isinstance(input, LazyLogits) and input._dense is None:
+        raw = input._before_raw
+        if raw.is_contiguous() and ops.seg_loss_fused_ok(raw.shape[1], raw.shape[2], target.shape[-2], target.shape[-1], input._nc) \
+                and tuple(target.shape[-2:]) == input._size:
+            return _SegLossFusedFn.apply(raw, input._nc, target, ldw, cw, mode, gamma, ignore, reduce_fn)
+    if isinstance(input, LazyLogits):
+        input = input.materialize()
+    if input.shape[-2:] != target.shape[-2:]:
+        input = _UpsampleNCHWFn.apply(input, tuple(target.shape[-2:]))
+    return _SegLossFn.apply(input, target, ldw, cw, mode, gamma, ignore, reduce_fn)
+
+
 def _prep_target(target):
     ops.require_device(target, "target")
     if target.dtype != torch.int64:
@@ -154,11 +249,9 @@ class BoundaryAwareFocalLoss(nn.Module):
         return "full"
 
     def forward(self, input, target, batch, **kwargs):
-        if input.shape[-2:] != target.shape[-2:]:
-            input = _UpsampleNCHWFn.apply(input, tuple(target.shape[-2:]))
         ldw = batch["label_distance_weight"].to(input.device, input.dtype).contiguous()
-        loss = _SegLossFn.apply(input, _prep_target(target), ldw, self._class_weight(input.device), self._mode(),
-                                float(self.gamma), int(self.ignore_id), self.dist_reduce)
+        loss = _seg_loss(input, target, ldw, self._class_weight(input.device), self._mode(), float(self.gamma),
+                         int(self.ignore_id), self.dist_reduce)
         self.step_counter += 1
         return loss
 
@@ -182,11 +275,8 @@ class SemsegCrossEntropy(nn.Module):
         self.dist_reduce = None
 
     def forward(self, logits, labels, **kwargs):
-        if logits.shape[-2:] != labels.shape[-2:]:
-            logits = _UpsampleNCHWFn.apply(logits, tuple(labels.shape[-2:]))
         self.step_counter += 1
-        return _SegLossFn.apply(logits, _prep_target(labels), None, None, "ce", 0.0, int(self.ignore_id),
-                                self.dist_reduce)
+        return _seg_loss(logits, labels, None, None, "ce", 0.0, int(self.ignore_id), self.dist_reduce)
 
 
 # --------------------------------------------------------------------------- #

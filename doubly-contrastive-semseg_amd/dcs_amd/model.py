@@ -235,7 +235,8 @@ class SwiftNetEngine:
         self._nbt = []
 
     # ---- forward ---------------------------------------------------------
-    def forward(self, img, training: bool, supcon: bool, need_grad: bool):
+    def forward(self, img, training: bool, supcon: bool, need_grad: bool, lazy_seg: bool = False):
+        """lazy_seg: do not materialise the full-resolution logits (the caller wraps ``before`` in losses.LazyLogits)."""
         fe = self.fe
         self._mean = fe.img_mean.reshape(3).contiguous()
         self._std = fe.img_std.reshape(3).contiguous()
@@ -285,7 +286,7 @@ class SwiftNetEngine:
             bnh = self._bn(ff0, self.seg.norm, training, rows=B * h * w)
             zh = ops.bn_act(ff0, bnh, relu=True)
             before = ops.conv_fwd(zh, self.seg.conv.weight, 1, 0, bias=self.seg.conv.bias, dst_cs=LOGIT_CS)
-            seg = ops.upsample_to_nchw(before, self.num_classes, H, W)
+            seg = None if lazy_seg else ops.upsample_to_nchw(before, self.num_classes, H, W)
             if need_grad:
                 tape.append(("head", ff0, bnh, zh, (H, W)))
         self._flush_nbt()
@@ -459,10 +460,10 @@ class _SwiftNetFn(torch.autograd.Function):
     through autograd's split-backward (a 2 GB cat + add per step at C3))."""
 
     @staticmethod
-    def forward(ctx, engine: SwiftNetEngine, img, training, supcon, grad_enabled, *params):
+    def forward(ctx, engine: SwiftNetEngine, img, training, supcon, grad_enabled, lazy_seg, *params):
         need_grad = grad_enabled and any(p.requires_grad for p in params)
         ctx.set_materialize_grads(False)
-        seg, before, ff, saved = engine.forward(img, training, supcon, need_grad)
+        seg, before, ff, saved = engine.forward(img, training, supcon, need_grad, lazy_seg)
         ctx.engine, ctx.saved, ctx.params = engine, saved, params
         B = ff.shape[0] // 2 if supcon else ff.shape[0]
         ff0 = ff[:B] if supcon else ff.view(ff.shape)
@@ -506,7 +507,7 @@ class _SwiftNetFn(torch.autograd.Function):
                 res.append(None)
             else:
                 res.append(gp)
-        return (None, None, None, None, None) + tuple(res)
+        return (None, None, None, None, None, None) + tuple(res)
 
 
 class WeatherNet(nn.Module):
@@ -557,8 +558,12 @@ class WeatherNet(nn.Module):
         for t in (left_img if isinstance(left_img, (list, tuple)) else [left_img]):
             ops.require_device(t, "left_img")
         params = [p for p in self.parameters()]
+        # training with autograd on: pred_segmap is a LazyLogits handle (losses.py) -- the criteria evaluate it fused,
+        # any other use materialises it; opts.lazy_pred_segmap = False restores the eager 2.55 GB tensor
+        lazy = bool(self.training and torch.is_grad_enabled() and self.segmentation is not None and
+                    getattr(self.opts, "lazy_pred_segmap", True))
         seg, before, ff, ff0 = _SwiftNetFn.apply(self._get_engine(), left_img, self.training,
-                                                 bool(return_supcon_feature), torch.is_grad_enabled(), *params)
+                                                 bool(return_supcon_feature), torch.is_grad_enabled(), lazy, *params)
         # NHWC buffers exposed with the reference's logical NCHW shapes (channels_last strides, no copy);
         # fine_feat0 is the first half of fine_feat (weathernet.py:78-82) and shares its memory
         fine_feat = ff.permute(0, 3, 1, 2)
@@ -566,6 +571,10 @@ class WeatherNet(nn.Module):
         if self.segmentation is None:
             return None, None, fine_feat, fine_feat0
         pred_segmap_beforeup = before[..., :self.num_classes].permute(0, 3, 1, 2)
+        if lazy:
+            from .losses import LazyLogits
+            first = left_img[0] if isinstance(left_img, (list, tuple)) else left_img
+            seg = LazyLogits(before, self.num_classes, first.shape[-2:])
         return seg, pred_segmap_beforeup, fine_feat, fine_feat0
 
     def random_init_params(self):

@@ -555,6 +555,29 @@ def seg_loss(logits, target, ldw, cw, mode, gamma=0.5, ignore=255):
     return out, grad
 
 
+def seg_loss_fused_ok(ih, iw, H, W, Cc):
+    """The fused upsample + loss kernel covers exact x2 / x4 upsampling of <= 20 classes."""
+    return Cc <= 20 and H % ih == 0 and W % iw == 0 and H // ih == W // iw and H // ih in (2, 4)
+
+
+def seg_loss_fused(logits_lr, Cc, target, ldw, cw, mode, gamma=0.5, ignore=255):
+    """logits_lr: NHWC low-resolution logits [N,ih,iw,cs] (first Cc channels used); target int64 [N,H,W].
+    Returns (out[3] = loss, count, 1/count ; grad_lr [N,ih,iw,cs] = unscaled d(sum loss)/d logits_lr)."""
+    _req(logits_lr)
+    if target.dtype != torch.int64 or not target.is_contiguous() or not target.is_cuda:
+        raise RuntimeError("seg_loss: target must be a contiguous int64 device tensor")
+    N, ih, iw, cs = logits_lr.shape
+    H, W = target.shape[1:]
+    grad = torch.empty_like(logits_lr)
+    blocks = N * (-(-ih // 8)) * (-(-iw // 32))
+    part = torch.empty((blocks, 2), device=logits_lr.device, dtype=_F32)
+    out = torch.empty((3,), device=logits_lr.device, dtype=_F32)
+    _call("dcs_seg_loss_fused", _p(logits_lr), cs, _p(target), _p(ldw), _p(cw), _p(grad), _p(part), N, Cc, ih, iw, H, W,
+          SEG_MODES[mode], float(gamma), int(ignore), blocks, _stream())
+    _call("dcs_seg_loss_final", _p(part), _p(out), blocks, _stream())
+    return out, grad
+
+
 def scale_inplace(x, a, b=None):
     _call("dcs_scale_inplace", _p(x), x.numel(), _p(a), _p(b), _stream())
     return x

@@ -9,6 +9,15 @@ by factors (measured: 1e-3 vs 8e-3 on the same gradient tensor), so the anchor f
 the reference's float32 execution paths available in the build container (oneDNN, oneDNN disabled, channels_last).
 ``floor`` only guards quantities on which the reference happens to be exact to the last bit (short gradient paths).
 
+Families of tensors (``family`` / ``finish_family``).  A network with ReLUs is not a continuous function of its
+rounding errors: on the small fixtures (deepest maps of 2x3 .. 8x16 pixels) one ReLU whose pre-activation is within fp32
+noise of zero flips between two float32 evaluations and changes every gradient behind it by ~1/sqrt(#samples) ~ 1e-2.
+Measured on 30 (criterion, seed) fixtures: the reference's OWN two float32 paths (oneDNN vs ATen-native convolution)
+differ from each other by 3x .. 269x in error on at least one gradient tensor on EVERY fixture.  A per-tensor ratio
+bound is therefore violated by the reference against itself; the meaningful statements, both with the same K, are:
+  (i)  the MEDIAN over the family of err_hip(t) / e32(t) is <= K  (typical tensors track the reference's error), and
+  (ii) every tensor satisfies err_hip(t) <= K * max_t' e32(t')   (nothing is worse than K x the reference's worst).
+
 Every comparison is also appended to a report (``gpurun_out/parity/<name>.json`` when that directory can be
 written) so the realised ratios are on record, and failures are collected and raised together at the end of a test.
 """
@@ -52,6 +61,28 @@ class Budget:
         if not eh <= bound:
             self.failures.append(f"{what}: err {eh:.3e} > {k} x max(ref32 err {e32:.3e}, floor {floor:.1e})")
         return eh, e32
+
+    def family(self, fam, what, mine, ref32, ref64, metric=rel_l2, e32=None, floor=1e-7):
+        """Collect one tensor of a family (see the module docstring); judged by finish_family."""
+        e = metric(ref32, ref64) if e32 is None else max(float(e32), metric(ref32, ref64))
+        eh = metric(mine, ref64)
+        self.rows.append(dict(what=what, family=fam, err_hip=eh, err_ref32=e, ratio=eh / max(e, floor)))
+
+    def finish_family(self, fam, k=K):
+        rows = [r for r in self.rows if r.get("family") == fam]
+        if not rows:
+            return
+        med = float(np.median([r["ratio"] for r in rows]))
+        worst_ref = max(r["err_ref32"] for r in rows)
+        worst = max(rows, key=lambda r: r["err_hip"])
+        self.rows.append(dict(what="family " + fam, tensors=len(rows), median_ratio=med, worst_ref32=worst_ref,
+                              worst_hip=worst["err_hip"], worst_hip_tensor=worst["what"]))
+        if not med <= k:
+            self.failures.append(f"{fam}: median err_hip/err_ref32 over {len(rows)} tensors = {med:.2f} > {k}")
+        for r in rows:
+            r["bound"] = k * worst_ref
+            if not r["err_hip"] <= k * worst_ref:
+                self.failures.append(f"{r['what']}: err {r['err_hip']:.3e} > {k} x the reference's worst tensor error {worst_ref:.3e}")
 
     def check_abs(self, what, err, bound):
         self.rows.append(dict(what=what, err_hip=float(err), bound=float(bound)))

@@ -294,6 +294,24 @@ def seg_loss(logits, target, ldw, cw, mode, gamma=0.5, ignore=255):
     return out, grad
 
 
+def seg_loss_fused_ok(ih, iw, H, W, Cc):
+    return Cc <= 20 and H % ih == 0 and W % iw == 0 and H // ih == W // iw and H // ih in (2, 4)
+
+
+def seg_loss_fused(logits_lr, Cc, target, ldw, cw, mode, gamma=0.5, ignore=255):
+    """Contract of dcs_seg_loss_fused: upsample the NHWC low-resolution logits, apply seg_loss, fold the gradient back."""
+    N, ih, iw, cs = logits_lr.shape
+    H, W = target.shape[1:]
+    x = logits_lr[..., :Cc].detach().clone().requires_grad_(True)
+    with torch.enable_grad():
+        up = F.interpolate(x.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False)
+    out, g = seg_loss(up.detach().contiguous(), target, ldw, cw, mode, gamma, ignore)
+    (gx,) = torch.autograd.grad(up, x, g)
+    grad = torch.zeros_like(logits_lr)
+    grad[..., :Cc] = gx
+    return out, grad
+
+
 def scale_inplace(x, a, b=None):
     x.mul_(a[0] * (b[0] if b is not None else 1.0))
     return x

@@ -154,7 +154,7 @@ def run_and_check_step(ts, g, criterion, shape, rng_seed, rtol, device="cpu", gr
             if g64 is None:
                 close_l2(params[key[6:]].grad, g[key], grad_rtol, key)
             else:
-                bud.check(key, params[key[6:]].grad, g[key], g64[key], metric=rel_l2, floor=1e-5, e32=e32_of(key))
+                bud.family("stored gradient tensors", key, params[key[6:]].grad, g[key], g64[key], e32=e32_of(key))
         if key.startswith("post::"):
             v = sd[key[6:]]
             if "num_batches" in key:
@@ -177,11 +177,13 @@ def run_and_check_step(ts, g, criterion, shape, rng_seed, rtol, device="cpu", gr
             if g64 is None:
                 close_l2(gp, g[f"proj_grad_{i}"], grad_rtol, f"proj{i}")
             else:
-                bud.check(f"proj_grad_{i}", gp, g[f"proj_grad_{i}"], g64[f"proj_grad_{i}"], metric=rel_l2, floor=1e-5,
-                          e32=e32_of(f"proj_grad_{i}"))
+                bud.family("projection-head gradients", f"proj_grad_{i}", gp, g[f"proj_grad_{i}"], g64[f"proj_grad_{i}"],
+                           e32=e32_of(f"proj_grad_{i}"))
     pn = {str(k): float(v) for k, v in zip(g["post_names"], g["post_norms"])}
     for k, v in pn.items():
         mine = float(sd[k].double().norm())
         assert abs(mine - v) <= 1e-3 * max(v, 1.0), (k, mine, v)
+    bud.finish_family("stored gradient tensors")
+    bud.finish_family("projection-head gradients")
     bud.finish()
     return out

@@ -1,12 +1,15 @@
 """GPU: DeepLabV3+/ResNet-101 (BASELINE config 5) train step on the HIP kernels against the reference golden and the
-oracle.  Tolerances: the reference's own fp32-vs-fp64 forward differs by 2e-3 (logits) on this 101-layer model, so
-fp32 comparisons use 1e-2 of max for logits, 5e-3 for features/losses, 1e-1 on gradient norms (the reference's own fp32 and fp64 gradient norms differ by up to 4.2e-2 here)."""
+oracle.  No tolerance constants: on this randomly initialised 101-layer model with batch 2 the reference's OWN float32
+result is 2e-3 (logits) / 4e-2 (gradient norms) / 131 argmax pixels away from its float64 result, so every quantity is
+held to K = 2 x the reference's float32 error measured over its float32 execution paths (tests/budget.py; anchors from
+tests/golden/make_golden_deeplab.py).  The golden test runs the materialised AND the lazy fine_feat0 path."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
+from budget import Budget, K, rel_l2, rel_max
 from oracle import deeplab_oracle as D
 from oracle import swiftnet_oracle as O
 from test_deeplab_oracle_golden import oracle_deeplab_step
@@ -41,41 +44,94 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def test_deeplab_step_matches_reference_golden(golden_dir):
+def _argmax_budget(bud, seg, g, g64):
+    """Class ids: every pixel that differs from the reference's float32 result must be one the reference itself cannot
+    decide in float32 (its margin <= 2K x its own fp32 logit error); the count may not exceed K x the reference's own
+    fp32-vs-fp64 count (+ a floor of 8 pixels)."""
+    am = seg.argmax(1).cpu().numpy().astype(np.uint8)
+    bad = am != g["seg_argmax"]
+    n_bad, n_ref = int(bad.sum()), int((g["seg_argmax"] != g64["seg_argmax"]).sum())
+    e32_abs = float(g64["e32::seg_logits_sub"]) * float(np.abs(g64["seg_logits_sub"]).max()) if "e32::seg_logits_sub" in g64.files \
+        else float(np.abs(g["seg_logits_sub"].astype(np.float64) - g64["seg_logits_sub"]).max())
+    worst = float(g["seg_margin"].astype(np.float64)[bad].max()) if n_bad else 0.0
+    bud.note("argmax", mismatches_hip_vs_ref32=n_bad, mismatches_ref32_vs_ref64=n_ref, pixels=int(bad.size),
+             worst_ref_margin_at_mismatch=worst, ref32_logit_abs_err=e32_abs)
+    bud.check_abs("argmax mismatch count", n_bad, K * n_ref + 8)
+    bud.check_abs("argmax worst reference margin at a mismatch", worst, 2 * K * e32_abs * 1.002)
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_deeplab_step_matches_reference_golden(golden_dir, lazy):
     g = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.npz"), allow_pickle=False)
+    g64 = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.f64.npz"), allow_pickle=False)
+    e32 = lambda k: g64["e32::" + k]
     b = 2
     img, labels, ldw, weather, cw = O.synthetic_batch(b, 128, 256, seed=51, two_crops=True, cell=32)
-    ts = build(b, cw)
+    ts = build(b, cw, lazy=lazy)
     s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
     torch.manual_seed(321)
     out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
+    bud = Budget(f"gpu_deeplab_step_b2_128x256_lazy{int(lazy)}")
+    # the very pixels the reference's sampler drew (identical argmax-derived hard/easy split and RNG consumption)
+    img_i, cls, pix, n_view = ts.pixelcontrast_criterion.last_anchors
+    assert np.array_equal(np.asarray(img_i), g["anchor_img"]) and np.array_equal(pix.cpu().numpy().T.astype(np.int32), g["anchor_pix"])
     for k in ("total", "supcon", "pixel", "seg"):
-        assert abs(float(out[k].detach()) - float(g[k])) <= 5e-3 * abs(float(g[k])), (k, float(out[k].detach()), float(g[k]))
-    assert rel(out["left_seg_beforeup"], g["before"]) < 1e-2
-    assert rel(out["fine_feat"][:, ::8], g["fine_feat_sub"]) < 5e-3
+        bud.check("loss " + k, float(out[k].detach()), float(g[k]), float(g64[k]), metric=rel_max, floor=1e-6, e32=float(e32(k)))
+    bud.check("before", out["left_seg_beforeup"], g["before"], g64["before"], metric=rel_max, e32=float(e32("before")))
+    bud.check("fine_feat", out["fine_feat"][:, ::8], g["fine_feat_sub"], g64["fine_feat_sub"], metric=rel_max,
+              e32=float(e32("fine_feat_sub")))
+    bud.check("seg logits", out["left_seg"][:, :, ::4, ::4], g["seg_logits_sub"], g64["seg_logits_sub"], metric=rel_max,
+              e32=float(e32("seg_logits_sub")))
+    _argmax_budget(bud, out["left_seg"], g, g64)
     params = dict(ts.model.named_parameters())
-    for k, n in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
-        gn = float(params[k].grad.norm())
-        assert abs(gn - n) <= 1e-1 * max(n, 1e-6) + 1e-7, (k, gn, n)   # reference fp32 vs fp64: up to 4.2e-2
+    names = [str(s) for s in g["grad_names"]]
+    e32n = e32("grad_norms")
+    worst_n = float(e32n.max())                       # norms are single numbers: see step_check.run_and_check_step
+    for i, (k, n) in enumerate(zip(names, g["grad_norms"])):
+        bud.check("|grad| " + k, float(params[k].grad.double().norm()), float(n), float(g64["grad_norms"][i]), metric=rel_max,
+                  floor=worst_n)
+    for key in g.files:
+        if key.startswith("grad::"):
+            gr = params[key[6:]].grad
+            mine = gr if gr.numel() < 400000 else gr.flatten()[::37]
+            bud.family("stored gradient tensors", key, mine, g[key], g64[key], e32=float(e32(key)))
     sd = ts.model.state_dict()
-    for k, n in zip([str(s) for s in g["rs_names"]], g["rs_norms"]):
-        assert abs(float(sd[k].double().norm()) - n) <= 2e-3 * max(n, 1.0), k
+    worst_rs = float(e32("rs_norms").max())
+    for i, (k, n) in enumerate(zip([str(s) for s in g["rs_names"]], g["rs_norms"])):
+        bud.check("|running| " + k, float(sd[k].double().norm()), float(n), float(g64["rs_norms"][i]), metric=rel_max,
+                  floor=max(worst_rs, 1e-6))
+    bud.finish_family("stored gradient tensors")
+    bud.finish()
 
 
 def test_deeplab_eval_forward_matches_reference_golden(golden_dir):
     g = np.load(os.path.join(golden_dir, "deeplab_eval_b1_104x168.npz"), allow_pickle=False)
+    g64 = np.load(os.path.join(golden_dir, "deeplab_eval_b1_104x168.f64.npz"), allow_pickle=False)
     ts = build(1, None)
     ts.model.eval()
     img = O.synthetic_batch(1, 104, 168, seed=52)[0]
     with torch.no_grad():
         seg, before, ff, ff0 = ts.model(img.to(DEV))
-    assert rel(before, g["before"]) < 1e-2
-    assert rel(ff[:, ::8], g["fine_feat_sub"]) < 5e-3
-    assert rel(ff0[:, ::16], g["fine_feat0_sub"]) < 5e-3
-    assert float((seg.argmax(1).cpu().numpy().astype(np.uint8) != g["seg_argmax"]).mean()) < 5e-3
+    bud = Budget("gpu_deeplab_eval_b1_104x168")
+    bud.check("before", before, g["before"], g64["before"], metric=rel_max)
+    bud.check("fine_feat", ff[:, ::8], g["fine_feat_sub"], g64["fine_feat_sub"], metric=rel_max)
+    bud.check("fine_feat0", ff0[:, ::16], g["fine_feat0_sub"], g64["fine_feat0_sub"], metric=rel_max)
+    am = seg.argmax(1).cpu().numpy().astype(np.uint8)
+    bad = am != g["seg_argmax"]
+    n_ref = int((g["seg_argmax"] != g64["seg_argmax"]).sum())
+    e32_abs = float(np.abs(g["before"].astype(np.float64) - g64["before"]).max())
+    worst = float(g["seg_margin"].astype(np.float64)[bad].max()) if bad.any() else 0.0
+    bud.note("argmax", mismatches_hip_vs_ref32=int(bad.sum()), mismatches_ref32_vs_ref64=n_ref, pixels=int(bad.size))
+    bud.check_abs("argmax mismatch count", int(bad.sum()), K * n_ref + 8)
+    bud.check_abs("argmax worst reference margin at a mismatch", worst, 2 * K * e32_abs * 1.002)
+    bud.finish()
 
 
-def test_deeplab_step_matches_oracle_and_trains():
+def test_deeplab_step_matches_oracle_and_trains(golden_dir):
+    """A second input (odd size 160x288) against the oracle.  The oracle's float64 run would sample other anchors here
+    (this model flips ~100 argmax pixels between fp32 and fp64), so the budget unit is borrowed from the golden fixture
+    of the same model and batch: K x the reference's float32 error measured there (tests/golden/deeplab_step_*.f64.npz)."""
+    g64 = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.f64.npz"), allow_pickle=False)
     b, h, w = 2, 160, 288
     img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=81, two_crops=True, cell=32)
     ts = build(b, cw)
@@ -84,12 +140,16 @@ def test_deeplab_step_matches_oracle_and_trains():
     out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
     state, proj = D.make_state(seed=7), O.make_proj(seed=9, dim_in=2048)
     ref, grads, _ = oracle_deeplab_step(state, proj, img, labels.clone(), ldw, weather, cw, b, 3)
-    assert abs(float(out["total"].detach()) - float(ref["total"])) <= 5e-3 * abs(float(ref["total"]))
-    assert rel(out["fine_feat"], ref["fine_feat"].numpy()) < 5e-3
-    assert rel(out["left_seg"], ref["seg_logits"].numpy()) < 1e-2
+    bud = Budget("gpu_deeplab_oracle_160x288")
+    # two fp32 evaluations are compared with each other here: each may be e32 away from the truth
+    bud.check_abs("total", abs(float(out["total"].detach()) - float(ref["total"])) / abs(float(ref["total"])),
+                  2 * K * float(g64["e32::total"]))
+    bud.check_abs("fine_feat", rel(out["fine_feat"], ref["fine_feat"].numpy()), 2 * K * float(g64["e32::fine_feat_sub"]))
+    bud.check_abs("seg logits", rel(out["left_seg"], ref["seg_logits"].numpy()), 2 * K * float(g64["e32::seg_logits_sub"]))
     params = dict(ts.model.named_parameters())
     worst = max(abs(float(params[k].grad.norm()) - float(gr.norm())) / max(float(gr.norm()), 1e-9) for k, gr in grads.items())
-    assert worst < 1e-1, worst
+    bud.check_abs("worst gradient norm", worst, 2 * K * float(g64["e32::grad_norms"].max()))
+    bud.finish()
     losses = []
     ts.model._get_engine().dropout_noise = None            # device-side dropout mask from here on
     for it in range(3):

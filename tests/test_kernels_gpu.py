@@ -76,7 +76,10 @@ def test_conv_fwd_dgrad_wgrad(ops, N, H, W, Cin, Cout, k, s):
     close(y, y_ref, what="fwd")
     y2, sums = ops.conv_fwd(x.to(DEV), cl(w.to(DEV)), s, pad, want_stats=True)
     close(y2, y_ref, what="fwd with stats epilogue")
-    close(sums, E.colsum(y_ref.reshape(-1, Cout)), 1e-5, "fused BN statistics")
+    from dcs_amd.ops import Moments
+    assert isinstance(sums, Moments)        # (mean, biased variance), formed in double from the epilogue's tile sums
+    close(sums[0, 0], E.colsum(y_ref.reshape(-1, Cout), moments=True)[0, 0], 1e-5, "fused BN statistics: mean")
+    close(sums[0, 1], E.colsum(y_ref.reshape(-1, Cout), moments=True)[0, 1], 1e-5, "fused BN statistics: variance")
     dy = rnd(*y_ref.shape, seed=3)
     wp_ref = E.pack_dgrad_weight(w)
     wp = ops.pack_dgrad_weight(cl(w.to(DEV)))
@@ -128,7 +131,8 @@ def test_stem_conv_and_wgrad(ops, N, H, W):
     y, sums = ops.stem_conv(p.to(DEV), wp, want_stats=True)
     yref = E.stem_conv(p, E.pack_stem_weight(w))
     close(y, yref, what="stem fwd")
-    close(sums, E.colsum(yref.reshape(-1, 64)), 1e-5, "stem fused BN statistics")
+    close(sums[0, 0], E.colsum(yref.reshape(-1, 64), moments=True)[0, 0], 1e-5, "stem fused BN statistics: mean")
+    close(sums[0, 1], E.colsum(yref.reshape(-1, 64), moments=True)[0, 1], 1e-5, "stem fused BN statistics: variance")
     dy = rnd(*yref.shape, seed=11)
     dwp = torch.empty(64, 7, 8, 4, device=DEV)
     ops.stem_wgrad(p.to(DEV), dy.to(DEV), dwp, False)
@@ -285,6 +289,44 @@ def test_seg_loss(ops, mode):
     assert torch.equal(t_dev.cpu(), t_ref)                      # in-place 255 -> 0 for focal modes only
     ops.scale_inplace(grad, torch.tensor([1.2], device=DEV), out[2:3])
     close(grad, grad_r * 1.2 * out_r[2], 1e-5, "scaled grad")
+
+
+@pytest.mark.parametrize("mode", ["full", "plain_focal", "no_class_weights", "no_EDT", "ce"])
+@pytest.mark.parametrize("N,ih,iw,F_", [(2, 13, 37, 4), (1, 8, 32, 4), (3, 50, 82, 4), (2, 9, 33, 2)])
+def test_seg_loss_fused(ops, mode, N, ih, iw, F_):
+    """dcs_seg_loss_fused (upsampling + log-softmax + focal/CE + adjoint of the upsampling in one kernel, nothing at full
+    resolution in memory) against upsample_to_nchw -> seg_loss -> upsample_to_nchw_bwd: partial tiles, image borders,
+    ignore pixels, the in-place 255 -> 0 rewrite, x2 and x4."""
+    if mode != "full" and (N, ih) != (2, 13):
+        pytest.skip("one geometry per non-default mode")
+    g = np.random.default_rng(61 + ih)
+    H, W = F_ * ih, F_ * iw
+    lr = torch.zeros(N, ih, iw, 20)
+    lr[..., :19] = rnd(N, ih, iw, 19, seed=62 + ih) * 2
+    lr[..., 19] = 7.0                                            # the pad channel must be ignored
+    tgt = torch.from_numpy(g.integers(0, 19, size=(N, H, W)).astype(np.int64))
+    tgt[:, :3, :] = 255
+    tgt[:, :, -2:] = 255
+    ldw = torch.from_numpy(g.random((N, H, W)).astype(np.float32))
+    ldw[tgt == 255] = 0
+    cw = torch.from_numpy((1.0 / np.log(1.1 + g.random(19) * 0.2)).astype(np.float32))
+    t_ref, t_dev = tgt.clone(), tgt.clone().to(DEV)
+    args = (None, None) if mode == "ce" else (ldw, cw)
+    out_r, grad_r = E.seg_loss_fused(lr.double(), 19, t_ref, *(a.double() if a is not None else None for a in args), mode)
+    dargs = tuple(a.to(DEV) if a is not None else None for a in args)
+    out, grad = ops.seg_loss_fused(lr.to(DEV), 19, t_dev, *dargs, mode)
+    close(out, out_r, 2e-6, "loss / count / 1/count")
+    close(grad[..., :19], grad_r[..., :19], 2e-5, "gradient of the low-resolution logits")
+    assert float(grad[..., 19].abs().max()) == 0.0
+    assert torch.equal(t_dev.cpu(), t_ref)                      # in-place 255 -> 0 for focal modes only
+    # the unfused kernels evaluate the same interpolation weights: same loss to rounding, and bitwise reproducible
+    t2 = tgt.clone().to(DEV)
+    up = ops.upsample_to_nchw(lr.to(DEV), 19, H, W)
+    out_u, grad_u = ops.seg_loss(up, t2, *dargs, mode)
+    close(out, out_u.cpu(), 1e-6, "fused vs unfused loss")
+    close(grad[..., :19], ops.upsample_to_nchw_bwd(grad_u, ih, iw, 20)[..., :19].cpu(), 2e-5, "fused vs unfused gradient")
+    out2, grad2 = ops.seg_loss_fused(lr.to(DEV), 19, tgt.clone().to(DEV), *dargs, mode)
+    assert torch.equal(out, out2) and torch.equal(grad, grad2)
 
 
 def test_seg_loss_no_valid_pixels(ops):

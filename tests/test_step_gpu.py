@@ -151,7 +151,7 @@ def test_train_step_matches_oracle(monkeypatch, criterion, two, b, h, w, ksplit)
         if gref is None:
             assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
             continue
-        bud.check("grad " + k, params[k].grad, gref, g64[k], metric=rel_l2, floor=1e-5, e32=rel_l2(grads_b[k], g64[k]))
+        bud.family("gradients", "grad " + k, params[k].grad, gref, g64[k], e32=rel_l2(grads_b[k], g64[k]))
         bud.check("|grad| " + k, float(params[k].grad.double().norm()), float(gref.double().norm()), float(g64[k].norm()),
                   metric=rel_max, floor=worst_n)
     sd = ts.model.state_dict()
@@ -160,6 +160,7 @@ def test_train_step_matches_oracle(monkeypatch, criterion, two, b, h, w, ksplit)
             close(sd[k], v.numpy(), RTOL, k)
         if "num_batches" in k:
             assert int(sd[k]) == int(v), k
+    bud.finish_family("gradients")
     bud.finish()
 
 
