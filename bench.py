@@ -11,7 +11,8 @@ Workload at N=1 = BASELINE.json configs[2] ("C3"): B=16 labelled images (32 crop
 2048x1024, criterion supcon_pixelcontrast_focal -- the configuration the metric is quoted on; it fits one GPU.
 Weak scaling: every rank keeps B=16.
 
-roofline: dominant kernel = the implicit-GEMM conv kernel (forward + data gradient launches, conv_gather_kernel).
+roofline: dominant kernel = the implicit-GEMM conv kernel (forward + data gradient launches, conv_gather_kernel,
+EVERY launch: plain and split-K).
 achieved = algorithmic FLOPs (2*M*taps*K*Cout per launch) / summed launch time measured with HIP
 events recorded on the launch stream during the timed steps.  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
 cpu_baseline: the oracle (pure-PyTorch CPU restatement, kind "port") on a bounded sample of the same workload.
@@ -73,8 +74,9 @@ class ConvProfiler:
         self._orig = ops._call
 
         def wrapped(name, *args):
-            if self.enabled and name in ("dcs_conv_gather", "dcs_conv_wgrad"):
-                g = args[4]._obj if name == "dcs_conv_gather" else args[3]._obj
+            # every launch of the implicit-GEMM kernels: plain, split-K (its slab reduce is timed with it) and wgrad
+            if self.enabled and name in ("dcs_conv_gather", "dcs_conv_gather_split", "dcs_conv_wgrad"):
+                g = args[3]._obj if name != "dcs_conv_gather" else args[4]._obj
                 M = g.N * g.TY * g.TX
                 flops = 2.0 * M * (147 if g.stem else g.ntaps * g.K) * g.Cout
                 # algorithmic bytes: gathered tensor once + produced tensor once + weights once
@@ -83,8 +85,9 @@ class ConvProfiler:
                 e0.record()
                 self._orig(name, *args)
                 e1.record()
-                key = (name, g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy, g.stem)
-                self.records.append((name, flops, e0, e1, key, abytes))
+                kind = "dcs_conv_wgrad" if name == "dcs_conv_wgrad" else "dcs_conv_gather"
+                key = (kind, g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy, g.stem)
+                self.records.append((kind, flops, e0, e1, key, abytes))
             else:
                 self._orig(name, *args)
         ops._call = wrapped
@@ -153,45 +156,37 @@ def pmc_traffic(args, world):
 
 
 def similarity_bench(ops, dev, ts, reps=20):
-    """BASELINE.json's second metric: TFLOP/s of the embedding-similarity kernels of the pixel-contrastive loss
-    (S = X X^T forward, dX = (G + G^T) X backward; utils/loss.py:339-389), outside the timed region, HIP events.
-    A = anchors this rank sampled in the last step (<= 608 rows of 128) and A_global = the 8-rank gathered set of C4."""
+    """BASELINE.json's second metric: TFLOP/s of the pixel-contrastive similarity / InfoNCE loss, forward AND backward
+    (utils/loss.py:339-389), outside the timed region, HIP events.  Algorithmic FLOPs = 2 A^2 d (S = X X^T) +
+    4 A^2 d (dX = (G + G^T) X) = 6 A^2 d; the fused kernels execute more than that (S tiles are
+    recomputed instead of stored: contrast_fused.hip).  A = anchors this rank sampled in the last step (<= 608 rows of
+    128: two launches) and A_global = the 8-rank gathered set of C4 (4864 rows: symmetric tile sweeps).
+    `unfused_*` = the round-1 chain (GEMM writes S, row kernel, symmetrize, transpose, GEMM) on the same data."""
     la = ts.pixelcontrast_criterion.last_anchors
     a_rank = int(la[2].numel()) if la is not None else 608
-    out = {"unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS, "dim": 128}
+    out = {"unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS, "dim": 128,
+           "flops": "algorithmic 6*A^2*128 (fwd 2*A^2*128 + bwd 4*A^2*128)"}
     for tag, A in (("rank", a_rank), ("global", 8 * a_rank)):
         gen = torch.Generator(device="cpu").manual_seed(A)
         X = torch.nn.functional.normalize(torch.randn(A, 128, generator=gen), dim=1).to(dev)
         y = torch.randint(0, 19, (A,), generator=gen).float().to(dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-        for _ in range(3):
-            ops.contrast_fwd_bwd(X, y, 0, 0.07)
-        ev[0].record()
-        for _ in range(reps):
-            ops.contrast_fwd_bwd(X, y, 0, 0.07)
-        ev[1].record()
-        torch.cuda.synchronize()
-        us = ev[0].elapsed_time(ev[1]) / reps * 1e3
-        flops = 6.0 * A * A * 128                       # fwd 2 A^2 d + bwd 4 A^2 d (SURVEY.md 8(d))
-        # the two GEMMs alone (the rest of the loss is row reductions)
-        ld = -(-A // 32) * 32
-        Gs = torch.randn(A, ld, generator=gen).to(dev)
-        dXp = torch.empty((ld, 128), device=dev)
-        Xt = ops.transpose(X if ld == A else torch.cat([X, X.new_zeros(ld - A, 128)]))
-        bwd = (lambda: ops.linear_wgrad(X, Gs, dXp)) if A > 1024 else (lambda: ops.linear(Gs, Xt))   # as contrast_fwd_bwd
-        tg = []
-        for fn in (lambda: ops.linear(X, X), bwd):
-            fn(); ev[0].record()
+        res = {"A": A}
+        for name, fn in (("loss", ops.contrast_fwd_bwd), ("unfused_loss", ops.contrast_fwd_bwd_unfused)):
+            for _ in range(3):
+                fn(X, y, 0, 0.07)
+            ev[0].record()
             for _ in range(reps):
-                fn()
-            ev[1].record(); torch.cuda.synchronize()
-            tg.append(ev[0].elapsed_time(ev[1]) / reps * 1e3)
-        out[tag] = {"A": A, "loss_fwd_bwd_us": us, "loss_tflops": flops / us / 1e6,
-                    "gemm_fwd_us": tg[0], "gemm_fwd_tflops": 2.0 * A * A * 128 / tg[0] / 1e6,
-                    "gemm_bwd_us": tg[1], "gemm_bwd_tflops": 2.0 * A * ld * 128 / tg[1] / 1e6}
+                fn(X, y, 0, 0.07)
+            ev[1].record()
+            torch.cuda.synchronize()
+            us = ev[0].elapsed_time(ev[1]) / reps * 1e3
+            res[name + "_fwd_bwd_us"] = us
+            res[name + "_tflops"] = 6.0 * A * A * 128 / us / 1e6
+        out[tag] = res
     gl = out["global"]
-    out["similarity_kernel_frac_global"] = gl["gemm_fwd_tflops"] / PEAK_FP32_MFMA_TFLOPS    # S = X X^T at the C4 size
-    out["note"] = "rank-size kernels (A <= 608) are launch-latency bound: 95 MFLOP = 0.6 us at peak"
+    out["similarity_kernel_frac_global"] = gl["loss_tflops"] / PEAK_FP32_MFMA_TFLOPS     # whole fused loss at the C4 size
+    out["note"] = "rank size (A <= 608): 95 MFLOP = 0.6 us at peak, i.e. launch-latency bound: two launches"
     return out
 
 

@@ -26,6 +26,7 @@
 // (what the f32 MFMA is) loses them where the reference's blocked CPU GEMM does not (measured: 7x the reference's own
 // fp32-vs-fp64 error on the projection-head gradients; with f64 accumulation 0.1x).  2B <= 512 rows: free.
 #include "dcs_common.h"
+#include <cstdlib>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef double f64x4 __attribute__((ext_vector_type(4)));
@@ -52,6 +53,11 @@ template <> struct Mfma16<double> {
 };
 
 __device__ __forceinline__ float4 ldg4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+// exp of a normalised logit L in [-1, 0]: v_exp_f32 (1 ulp) of L * log2(e); the argument rounding adds <= 9e-8 relative.
+// The epilogues evaluate two of these per similarity element, the library expf (range reduction, denormal handling) is
+// ~4x the instructions.
+__device__ __forceinline__ float exp_unit(float L) { return __expf(L); }
+__device__ __forceinline__ float rcp_fast(float x) { return __frcp_rn(x); }
 __device__ __forceinline__ float comp(const float4& v, int c) { return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w)); }
 
 // One 16x16 tile of S = X_I X_J^T.  Lane (r = lane&15, q = lane>>4) holds, per 16-channel step s, the float4
@@ -78,6 +84,25 @@ __device__ __forceinline__ typename Mfma16<ACC>::acc_t s_tile(const float4 (&xa)
       for (int c = 0; c < 4; ++c) acc = Mfma16<ACC>::mma(comp(xs[s], c), comp(xb[s], c), acc);
   }
   return acc;
+}
+
+// C <= 128: both operands already in registers
+template <typename ACC>
+__device__ __forceinline__ typename Mfma16<ACC>::acc_t s_tile_regs(const float4 (&xa)[8], const float4 (&xb)[8]) {
+  typename Mfma16<ACC>::acc_t acc = Mfma16<ACC>::zero();
+#pragma unroll
+  for (int s = 0; s < 8; ++s)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc = Mfma16<ACC>::mma(comp(xa[s], c), comp(xb[s], c), acc);
+  return acc;
+}
+__device__ __forceinline__ void load_rows8(float4 (&x)[8], const float* __restrict__ X, const int ldx, const int C, const int row,
+                                           const int q) {
+#pragma unroll
+  for (int s = 0; s < 8; ++s) {
+    const int k = 16 * s + 4 * q;
+    x[s] = (row >= 0 && k < C) ? ldg4(X + (long long)row * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 }
 
 template <int W>
@@ -127,11 +152,26 @@ void contrast_small_stats_kernel(const float* __restrict__ X, const int ldx, con
     xa[s] = (rowI >= 0 && k < C) ? ldg4(X + (long long)rowI * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int ntile = (A + 15) >> 4;
-  for (int jt = wid; jt < ntile; jt += NW) {
-    const int rowJ = 16 * jt + li < A ? 16 * jt + li : -1;
-    const typename Mfma16<ACC>::acc_t acc = s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
+  if (C <= 128) {
+    // software prefetch: the next column tile's rows are in flight (L2) while this tile's 32 MFMAs issue
+    float4 xn[8];
+    if (wid < ntile) load_rows8(xn, X, ldx, C, 16 * wid + li < A ? 16 * wid + li : -1, q);
+    for (int jt = wid; jt < ntile; jt += NW) {
+      float4 xb[8];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) Ss[Mfma16<ACC>::row(lane, r) * AP + 16 * jt + li] = acc[r];
+      for (int s = 0; s < 8; ++s) xb[s] = xn[s];
+      if (jt + NW < ntile) load_rows8(xn, X, ldx, C, 16 * (jt + NW) + li < A ? 16 * (jt + NW) + li : -1, q);
+      const typename Mfma16<ACC>::acc_t acc = s_tile_regs<ACC>(xa, xb);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ss[Mfma16<ACC>::row(lane, r) * AP + 16 * jt + li] = acc[r];
+    }
+  } else {
+    for (int jt = wid; jt < ntile; jt += NW) {
+      const int rowJ = 16 * jt + li < A ? 16 * jt + li : -1;
+      const typename Mfma16<ACC>::acc_t acc = s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Ss[Mfma16<ACC>::row(lane, r) * AP + 16 * jt + li] = acc[r];
+    }
   }
   __syncthreads();
 
@@ -160,7 +200,7 @@ void contrast_small_stats_kernel(const float* __restrict__ X, const int ldx, con
     const float yj = ys[j];
     if (yj < 0.f) continue;
     const float L = (float)(srow[j] * itA - m) * rn;
-    const float E = expf(L);
+    const float E = exp_unit(L);
     if (mode == 0) {
       if (yj != yi) { den += E; sEL = fmaf(E, L, sEL); }               // neg_logits (:376-377)
       else if (j != i) cnt += 1.f;
@@ -181,8 +221,8 @@ void contrast_small_stats_kernel(const float* __restrict__ X, const int ldx, con
     for (int j = rl; j < A; j += TPR) {
       if (j == i || ys[j] != yi) continue;
       const float L = (float)(srow[j] * itA - m) * rn;
-      const float d = expf(L) + den;
-      const float id = 1.f / d;
+      const float d = exp_unit(L) + den;
+      const float id = rcp_fast(d);
       slp += L - logf(d); sq += id; sdl = fmaf(den * id, L, sdl);
     }
     lp = grp_sum<TPR>(slp); qv = grp_sum<TPR>(sq); sdl = grp_sum<TPR>(sdl);
@@ -212,10 +252,10 @@ __device__ __forceinline__ float g_entry(const ACC s, const float* __restrict__ 
                                          const int mode, const bool same, const bool self, const float w) {
   const float rn = ra[2], den = ra[3], icnt = ra[4], qv = ra[5], dot = ra[6];
   const float L = (float)(s * itA - rec_get_m<ACC>(ra)) * rn;
-  const float E = expf(L);
+  const float E = exp_unit(L);
   float dL;
-  if (mode == 0) dL = same ? (self ? 0.f : -(den / (E + den)) * icnt) : E * qv * icnt;
-  else dL = self ? 0.f : (E / den - w * icnt);
+  if (mode == 0) dL = same ? (self ? 0.f : -(den * rcp_fast(E + den)) * icnt) : E * qv * icnt;
+  else dL = self ? 0.f : (E * rcp_fast(den) - w * icnt);
   const float du = ra[7] != 0.f ? dL : dL - L * dot;                  // through F.normalize (clamped norm: no projection)
   return du * rn * it;
 }
@@ -267,17 +307,29 @@ void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, con
   float* xt = Xt + wid * 16 * XLD;
   const ACC itA = (ACC)it;
   const int ntile = (A + 15) >> 4;
+  const bool regs = C <= 128;
+  // software prefetch of the next column tile: its rows, record and label are in flight while this tile computes
+  float4 xn[8], rna, rnb;
+  float yn = -1.f;
+  auto prefetch = [&](int jt) {
+    const int j = 16 * jt + li;
+    const bool ok = jt < ntile && j < A;
+    if (regs) load_rows8(xn, X, ldx, C, ok ? j : -1, q);
+    rna = ok ? ldg4(rec + (long long)j * REC) : make_float4(0.f, 0.f, 0.f, 0.f);
+    rnb = ok ? ldg4(rec + (long long)j * REC + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    yn = ok ? y[(long long)j * ldy] : -1.f;
+  };
+  prefetch(wid);
   for (int jt = wid; jt < ntile; jt += NW) {
     const int j = 16 * jt + li;
     const int rowJ = j < A ? j : -1;
-    const typename Mfma16<ACC>::acc_t acc = s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
-    float rj[REC];
-    const float yj = rowJ >= 0 ? y[(long long)j * ldy] : -1.f;
-    {
-      const float4 a = rowJ >= 0 ? ldg4(rec + (long long)j * REC) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 b = rowJ >= 0 ? ldg4(rec + (long long)j * REC + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      rj[0] = a.x; rj[1] = a.y; rj[2] = a.z; rj[3] = a.w; rj[4] = b.x; rj[5] = b.y; rj[6] = b.z; rj[7] = b.w;
-    }
+    float4 xb[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) xb[s] = xn[s];
+    const float rj[REC] = {rna.x, rna.y, rna.z, rna.w, rnb.x, rnb.y, rnb.z, rnb.w};
+    const float yj = yn;
+    prefetch(jt + NW);
+    const typename Mfma16<ACC>::acc_t acc = regs ? s_tile_regs<ACC>(xa, xb) : s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int il = Mfma16<ACC>::row(lane, r);
@@ -295,17 +347,10 @@ void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, con
       else gt[il * GLD + li] = gs;
     }
     if (gsym_out) continue;
-    // X_J tile -> per-wave LDS image [16 j][XLD] (the k-strided B operand of the second product)
-    {
-      const int nchunk = 1;                                            // C <= 128 on this path
-      (void)nchunk;
+    // X_J tile -> per-wave LDS image [16 j][XLD] (the k-strided B operand of the second product): the very registers
+    // that fed the S tile
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const int k = 16 * s + 4 * q;
-        const float4 v = (rowJ >= 0 && k < C) ? ldg4(X + (long long)rowJ * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        *reinterpret_cast<float4*>(&xt[li * XLD + k]) = v;
-      }
-    }
+    for (int s = 0; s < 8; ++s) *reinterpret_cast<float4*>(&xt[li * XLD + 16 * s + 4 * q]) = xb[s];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // dX_I[16][C] += Gsym[16 i][16 j] X_J[16 j][C]: A operand Gt[i = li][j = 4 kk + q], B operand xt[j = 4 kk + q][c = 16 ct + li]
@@ -391,6 +436,7 @@ struct StripParams {
   float* slab;                         // [nchunk][A][C] dX partials (phase 4)
   float* gsym; int ldg;                // phase 4 with C > 128: Gsym written out instead
   const float* av;                     // [1] number of valid rows
+  int dbg;                             // diagnostics (DCS_CONTRAST_DBG): 1 = skip the MFMAs, 2 = skip the epilogues
 };
 
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -418,14 +464,22 @@ template <int PHASE, int MODE>
 __global__ __launch_bounds__(256, 2)
 void contrast_strip_kernel(const StripParams p) {
   constexpr bool STATS = PHASE <= 3;
+  // the strip's own rows live in LDS next to the streamed X_J tile (the per-lane row accumulators / the dX accumulators
+  // need the registers).  PHASE 4 swaps the operand roles of the similarity product: A = the streamed tile (rows t),
+  // B = the resident strip (rows q), so that the Gsym values, written in place over the accumulators (rows t in the
+  // registers, q on the lanes), are DIRECTLY the A operand of the second product dX_Q[q][c] += sum_t Gsym[t][q] X_T[t][c]
+  // (v_mfma_f32_32x32x2: A lane (i = lane&31, k = lane>>5); register r of the two lane halves = the k pair
+  // row32(r,0), row32(r,1)): no transposition through LDS, no extra barrier.  Gsym is symmetric, so this is row block Q
+  // of (G + G^T) X.
+  constexpr bool ALDS = true;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* XJ = reinterpret_cast<float*>(smem_raw);                 // [64][XLDL]
-  float* recI = XJ + TB * XLDL;                                   // [64][REC]   (+ yI, rI in slots of their own)
+  float* XI = XJ + TB * XLDL;                                     // [64][XLDL] (ALDS only)
+  float* recI = XI + (ALDS ? TB * XLDL : 0);                      // [64][REC]   (+ yI, rI in slots of their own)
   float* recJ = recI + TB * REC;                                  // [64][REC]
   float* auxI = recJ + TB * REC;                                  // [64][2] = y_i, r_i
   float* auxJ = auxI + TB * 2;                                    // [64][2]
   float* red = auxJ + TB * 2;                                     // [2][64][4] cross-wave reduction scratch
-  float* Gs = red + 2 * TB * 4;                                   // [64][GLDL]  (phase 4)
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int A = p.A, C = p.C;
@@ -471,67 +525,87 @@ void contrast_strip_kernel(const StripParams p) {
       af[g] = (rowA >= 0 && k < C) ? ldg4(p.X + (long long)rowA * p.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  if (nkc == 1) load_a(0);
-  // X_J staging: thread -> 8 float4 of the [64][128] chunk image
+  if (!ALDS && nkc == 1) load_a(0);
+  // tile staging: thread -> 8 float4 of a [64][128] chunk image (rows of tile T, channels of chunk kc)
   float4 st[8];
-  auto load_j = [&](int J, int kc) {
+  auto load_j = [&](int T, int kc, bool valid) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int e = tid + 256 * q, r = e >> 5, k = kc * 128 + (e & 31) * 4;
-      const int row = J * TB + r;
-      st[q] = (J < jend && row < A && k < C) ? ldg4(p.X + (long long)row * p.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int row = T * TB + r;
+      st[q] = (valid && row < A && k < C) ? ldg4(p.X + (long long)row * p.ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
-  auto store_j = [&]() {
+  auto store_j = [&](float* dstT) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int e = tid + 256 * q, r = e >> 5, k4 = (e & 31) * 4;
-      *reinterpret_cast<float4*>(&XJ[r * XLDL + k4]) = st[q];
+      *reinterpret_cast<float4*>(&dstT[r * XLDL + k4]) = st[q];
     }
   };
+  if (ALDS && nkc == 1) { load_j(I, 0, true); store_j(XI); }
 
   // phase accumulators
   constexpr bool HAS3 = PHASE == 2 && MODE == 1;
   float ra0[16], ra1[16], ra2[16], ra3[HAS3 ? 16 : 1];           // row direction (stats phases), per-lane partials
-  f32x16 dacc[2];                                                // phase 4: dX strip, wave = rows 32 wm.., cols 64 wn + 32 b
+  f32x16 dacc[PHASE == 4 ? 4 : 1];                               // phase 4: dX rows 32 wn + .., channels 32 b + lane, partial over wm
 #pragma unroll
   for (int r = 0; r < 16; ++r) { ra0[r] = PHASE == 1 ? -3.0e38f : 0.f; ra1[r] = 0.f; ra2[r] = 0.f; if (HAS3) ra3[r] = 0.f; }
 #pragma unroll
-  for (int b = 0; b < 2; ++b)
+  for (int b = 0; b < (PHASE == 4 ? 4 : 1); ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dacc[b][r] = 0.f;
 
+  // software pipeline: the registers `st` hold the NEXT tile (issued right after the previous one was written to LDS),
+  // so its L2 / HBM latency is covered by this tile's MFMAs and epilogue
+  load_j(jbeg, 0, true);
+  // the tile's row records / labels / shifts ride the same pipeline: 2 + 2 floats per thread
+  float pr0 = 0.f, pr1 = 0.f, pa0 = -1.f, pa1 = 0.f;
+  auto load_aux = [&](int T, bool valid) {
+    const int r0 = T * TB + tid / REC, r1 = T * TB + (tid + 256) / REC;
+    pr0 = (PHASE >= 2 && valid && r0 < A) ? p.rec[(long long)T * TB * REC + tid] : 0.f;
+    pr1 = (PHASE >= 2 && valid && r1 < A) ? p.rec[(long long)T * TB * REC + tid + 256] : 0.f;
+    if (tid < TB) {
+      const int r = T * TB + tid;
+      pa0 = (valid && r < A) ? p.y[(long long)r * p.ldy] : -1.f;
+      pa1 = (valid && r < A) ? p.rnorm[r] : 0.f;
+    }
+  };
+  load_aux(jbeg, true);
   for (int J = jbeg; J < jend; ++J) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
     for (int kc = 0; kc < nkc; ++kc) {
-      load_j(J, kc);                                               // L2 latency is covered by the CU's other block
       __syncthreads();                                             // readers of the previous XJ image are done
-      store_j();
+      store_j(XJ);
       if (kc == 0) {
-        for (int e = tid; e < TB * REC; e += 256) {
-          const int r = J * TB + e / REC;
-          recJ[e] = (PHASE >= 2 && r < A) ? p.rec[(long long)J * TB * REC + e] : 0.f;
-        }
-        if (tid < TB) {
-          const int r = J * TB + tid;
-          auxJ[2 * tid] = r < A ? p.y[(long long)r * p.ldy] : -1.f;
-          auxJ[2 * tid + 1] = r < A ? p.rnorm[r] : 0.f;
-        }
+        recJ[tid] = pr0; recJ[tid + 256] = pr1;
+        if (tid < TB) { auxJ[2 * tid] = pa0; auxJ[2 * tid + 1] = pa1; }
       }
-      if (nkc > 1) load_a(kc);
+      if (nkc > 1) {
+        if (ALDS) { load_j(I, kc, true); store_j(XI); } else load_a(kc);
+      }
+      if (kc + 1 < nkc) load_j(J, kc + 1, true);
+      else { load_j(J + 1, 0, J + 1 < jend); load_aux(J + 1, J + 1 < jend); }                // prefetch
       __syncthreads();
-      const float* bj = &XJ[(32 * wn + l31) * XLDL + 4 * h];
+      if (p.dbg & 1) continue;
+      // phases 1-3: acc[r] = S[i = strip row 32 wm + row32(r,h)][j = tile row 32 wn + lane]
+      // phase 4:    acc[r] = S[t = tile row 32 wm + row32(r,h)][q = strip row 32 wn + lane]
+      const float* bj = &(PHASE == 4 ? XI : XJ)[(32 * wn + l31) * XLDL + 4 * h];
+      const float* ai = &(PHASE == 4 ? XJ : XI)[(32 * wm + l31) * XLDL + 4 * h];
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         const float4 b = *reinterpret_cast<const float4*>(bj + 8 * g);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].x, b.x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].y, b.y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].z, b.z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g].w, b.w, acc, 0, 0, 0);
+        float4 a;
+        if (ALDS) a = *reinterpret_cast<const float4*>(ai + 8 * g); else a = af[g];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
       }
     }
+    if (p.dbg & 2) continue;
     // ---- epilogue: lane holds S[i = 32 wm + row32(r, h)][j = 32 wn + l31], r = 0..15 ----
     const int jl = 32 * wn + l31, jg = J * TB + jl;
     const float yj = auxJ[2 * jl], rj = auxJ[2 * jl + 1];
@@ -571,7 +645,7 @@ void contrast_strip_kernel(const StripParams p) {
         const bool same = yi == yj, self = ig == jg;
         {                                                          // row i, column j
           const float L = (v - recI[il * REC]) * recI[il * REC + 2];
-          const float E = expf(L);
+          const float E = exp_unit(L);
           if (mode == 0) { if (!same) { ra0[r] += E; ra2[r] = fmaf(E, L, ra2[r]); } else if (!self) ra1[r] += 1.f; }
           else if (!self) {
             const float w = pos_weight(p.mask, p.mb, ig, jg, yi, yj);
@@ -580,7 +654,7 @@ void contrast_strip_kernel(const StripParams p) {
         }
         if (!diag) {                                               // row j, column i (S_ji = S_ij)
           const float L = (v - mj) * rnj;
-          const float E = expf(L);
+          const float E = exp_unit(L);
           if (mode == 0) { if (!same) { c0 += E; c2 = fmaf(E, L, c2); } else c1 += 1.f; }
           else {
             const float w = pos_weight(p.mask, p.mb, jg, ig, yj, yi);
@@ -610,13 +684,13 @@ void contrast_strip_kernel(const StripParams p) {
         {
           const float den = recI[il * REC + 3];
           const float L = (v - recI[il * REC]) * recI[il * REC + 2];
-          const float d = expf(L) + den, id = 1.f / d;
-          ra0[r] += L - logf(d); ra1[r] += id; ra2[r] = fmaf(den * id, L, ra2[r]);
+          const float d = exp_unit(L) + den, id = rcp_fast(d);
+          ra0[r] += L - __logf(d); ra1[r] += id; ra2[r] = fmaf(den * id, L, ra2[r]);
         }
         if (!diag) {
           const float L = (v - mj) * rnj;
-          const float d = expf(L) + denj, id = 1.f / d;
-          c0 += L - logf(d); c1 += id; c2 = fmaf(denj * id, L, c2);
+          const float d = exp_unit(L) + denj, id = rcp_fast(d);
+          c0 += L - __logf(d); c1 += id; c2 = fmaf(denj * id, L, c2);
         }
       }
       if (!diag) {
@@ -630,37 +704,34 @@ void contrast_strip_kernel(const StripParams p) {
         }
       }
     } else {
-      // PHASE 4: Gsym tile -> LDS (A operand of the second product) or -> global (wide features)
+      // PHASE 4 (roles swapped, see above): lane = strip row q, registers = tile rows t
+      const int ql = 32 * wn + l31, qg = i0 + ql;
+      const float yq = auxI[2 * ql];
+      float rq[REC];
+#pragma unroll
+      for (int e = 0; e < REC; ++e) rq[e] = recI[ql * REC + e];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int il = 32 * wm + row32(r, h), ig = i0 + il;
-        const float yi = auxI[2 * il];
+        const int tl = 32 * wm + row32(r, h), tg = J * TB + tl;
+        const float yt = auxJ[2 * tl];
         float gs = 0.f;
-        if (yi >= 0.f && yj >= 0.f) {
-          const bool same = yi == yj, self = ig == jg;
-          const float wij = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, ig, jg, yi, yj) : 0.f;
-          const float wji = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, jg, ig, yj, yi) : 0.f;
-          gs = (g_entry<float>(acc[r], recI + il * REC, it, it, mode, same, self, wij) +
-                g_entry<float>(acc[r], recJ + jl * REC, it, it, mode, same, self, wji)) * inv_av;
+        if (yq >= 0.f && yt >= 0.f) {
+          const bool same = yq == yt, self = qg == tg;
+          const float wqt = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, qg, tg, yq, yt) : 0.f;
+          const float wtq = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, tg, qg, yt, yq) : 0.f;
+          gs = (g_entry<float>(acc[r], rq, it, it, mode, same, self, wqt) +
+                g_entry<float>(acc[r], recJ + tl * REC, it, it, mode, same, self, wtq)) * inv_av;
         }
-        if (p.gsym) { if (ig < A && jg < A) p.gsym[(long long)ig * p.ldg + jg] = gs; }
-        else Gs[il * GLDL + jl] = gs;
+        if (p.gsym) { if (qg < A && tg < A) p.gsym[(long long)qg * p.ldg + tg] = gs; }
+        acc[r] = gs;
       }
       if (!p.gsym) {
-        __syncthreads();
-        // dX[32 wm + ..][64 wn + 32 b + ..] += sum_j Gs[i][j] XJ[j][c]:  A lane (i = l31, h): float4 Gs[i][8 g + 4 h ..];
-        // B lane (c = l31, h): XJ[8 g + 4 h + e][c] for the same four j (e = 0..3)
-        const float* ga = &Gs[(32 * wm + l31) * GLDL + 4 * h];
+        // dX_Q[q = lane][c = 32 b + n] += sum over this wave's 32 tile rows t of Gsym[t][q] X_T[t][c]
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-          const float4 a = *reinterpret_cast<const float4*>(ga + 8 * g);
-          const float av4[4] = {a.x, a.y, a.z, a.w};
+        for (int r = 0; r < 16; ++r) {
+          const float* xb = &XJ[(32 * wm + row32(r, h)) * XLDL + l31];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float* xb = &XJ[(8 * g + 4 * h + e) * XLDL + 64 * wn + l31];
-            dacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[e], xb[0], dacc[0], 0, 0, 0);
-            dacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av4[e], xb[32], dacc[1], 0, 0, 0);
-          }
+          for (int b = 0; b < 4; ++b) dacc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(acc[r], xb[32 * b], dacc[b], 0, 0, 0);
         }
       }
     }
@@ -690,17 +761,23 @@ void contrast_strip_kernel(const StripParams p) {
       o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = q0[3] + q1[3];
     }
   } else if (!p.gsym) {
+    // the two row halves (wm) of every tile hold partial sums for the same strip rows: add them through LDS (the tile
+    // images are free now), then one 16-byte store per lane into this chunk's slab
+    __syncthreads();
+    float* red2 = XJ;                                               // [2][64][XLDL] spans XJ and XI
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red2[(wm * TB + 32 * wn + row32(r, h)) * XLDL + 32 * b + l31] = dacc[b][r];
+    __syncthreads();
     const int chunk = jbeg / p.CH;
     float* o = p.slab + (long long)chunk * A * C;
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int c = 64 * wn + 32 * b + l31;
-      if (c >= C) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ig = i0 + 32 * wm + row32(r, h);
-        if (ig < A) o[(long long)ig * C + c] = dacc[b][r];
-      }
+    for (int e = tid; e < TB * 32; e += 256) {
+      const int ql = e >> 5, c4 = (e & 31) * 4;
+      if (i0 + ql >= A || c4 >= C) continue;
+      const float4 u = *reinterpret_cast<const float4*>(&red2[ql * XLDL + c4]);
+      const float4 v = *reinterpret_cast<const float4*>(&red2[(TB + ql) * XLDL + c4]);
+      *reinterpret_cast<float4*>(&o[(long long)(i0 + ql) * C + c4]) = make_float4(u.x + v.x, u.y + v.y, u.z + v.z, u.w + v.w);
     }
   }
 }
@@ -734,10 +811,30 @@ __global__ __launch_bounds__(256)
 void contrast_combine_kernel(const float* __restrict__ P, const float* __restrict__ y, int ldy, const float* __restrict__ rnorm,
                              const float* __restrict__ av, int A, int ntile, int CH, int mode, float* __restrict__ rec,
                              float* __restrict__ loss_row) {
-  const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r >= A) return;
-  float* rc = rec + (long long)r * REC;
-  const bool live = y[(long long)r * ldy] >= 0.f;
+  // 16 lanes per row: lane k sums slots k, k+16, ... (independent loads in flight), then a fixed-order butterfly
+  const int r = blockIdx.x * 16 + (threadIdx.x >> 4), k = threadIdx.x & 15;
+  const bool inrange = r < A;
+  const int rr = inrange ? r : A - 1;
+  float* rc = rec + (long long)rr * REC;
+  const bool live = inrange && y[(long long)rr * ldy] >= 0.f;
+  const int R = rr / TB;
+  double a1 = 0.0, a2 = 0.0, a3 = 0.0, a0 = PHASE == 1 ? -3.0e38 : 0.0;
+  if (live) {
+    // valid slots of row r: t < R (column-direction results of tiles (t, R)) and t = R + c * CH (row-direction chunks)
+    for (int t = k; t < ntile; t += 16) {
+      if (t >= R && ((t - R) % CH) != 0) continue;
+      const float4 v = ldg4(P + ((long long)t * A + rr) * 4);
+      if (PHASE == 1) a0 = fmax(a0, (double)v.x); else a0 += (double)v.x;
+      a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+    }
+  }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) {
+    const double b0 = __shfl_xor(a0, o, 64), b1 = __shfl_xor(a1, o, 64), b2 = __shfl_xor(a2, o, 64), b3 = __shfl_xor(a3, o, 64);
+    if (PHASE == 1) a0 = fmax(a0, b0); else a0 += b0;
+    a1 += b1; a2 += b2; a3 += b3;
+  }
+  if (k != 0 || !inrange) return;
   if (!live) {
     if (PHASE == 1) {
 #pragma unroll
@@ -746,15 +843,6 @@ void contrast_combine_kernel(const float* __restrict__ P, const float* __restric
     }
     return;
   }
-  const int R = r / TB;
-  double a1 = 0.0, a2 = 0.0, a3 = 0.0, a0 = PHASE == 1 ? -3.0e38 : 0.0;
-  auto add = [&](int slot) {
-    const float4 v = ldg4(P + ((long long)slot * A + r) * 4);
-    if (PHASE == 1) a0 = fmax(a0, (double)v.x); else a0 += (double)v.x;
-    a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
-  };
-  for (int t = 0; t < R; ++t) add(t);
-  for (int t = R; t < ntile; t += CH) add(t);
   if (PHASE == 1) {
     // n2 = sum (s - m)^2 = sum (s - r)^2 - 2 (m - r) sum (s - r) + A_v (m - r)^2, in double; 0 <= m - r <= range
     const double dm = a0 - (double)rnorm[r];
@@ -804,7 +892,8 @@ void contrast_finish_kernel(const float* __restrict__ slab, int nchunk, long lon
 }
 
 size_t strip_smem(int phase) {
-  return (size_t)(TB * XLDL + 2 * TB * REC + 4 * TB + 2 * TB * 4 + (phase == 4 ? TB * GLDL : 0)) * sizeof(float);
+  (void)phase;
+  return (size_t)(2 * TB * XLDL + 2 * TB * REC + 4 * TB + 2 * TB * 4) * sizeof(float);
 }
 
 int large_ws_floats(int A, int C, int64_t* out) {
@@ -828,6 +917,7 @@ int launch_large(const float* X, int ldx, const float* y, int ldy, const float* 
   StripParams p;
   p.X = X; p.ldx = ldx; p.y = y; p.ldy = ldy; p.mask = mask; p.mb = mb; p.A = A; p.C = C; p.mode = mode; p.ntile = ntile;
   p.it = it; p.rnorm = rnorm; p.rec = rec; p.P = P; p.slab = slab; p.gsym = gsym; p.ldg = ldg; p.av = av;
+  { const char* e = getenv("DCS_CONTRAST_DBG"); p.dbg = e ? atoi(e) : 0; }
   // statistics sweeps: ~3 blocks per CU.  chunks per strip I = ceil((ntile - I) / CH)
   int CH = 1;
   for (; CH < 16; ++CH) {
@@ -844,10 +934,16 @@ int launch_large(const float* X, int ldx, const float* y, int ldy, const float* 
     else hipLaunchKernelGGL((contrast_strip_kernel<PH, 1>), grid, block, sh, st, prm);                 \
   } while (0)
   hipLaunchKernelGGL(contrast_prep_kernel, dim3(256), dim3(256), 0, s, X, ldx, y, ldy, A, C, it, rnorm, av);
-  const dim3 cg((A + 255) / 256);
+  const dim3 cg((A + 15) / 16);
   auto set_attr = [](const void* f, size_t sh) {
     return sh <= 64 * 1024 || hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh) == hipSuccess;
   };
+  if (!set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<1, 0>), strip_smem(1)) ||
+      !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<1, 1>), strip_smem(1)) ||
+      !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<2, 0>), strip_smem(2)) ||
+      !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<2, 1>), strip_smem(2)) ||
+      !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<3, 0>), strip_smem(3)) ||
+      !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<3, 1>), strip_smem(3))) return DCS_E_LAUNCH;
   LAUNCH_STRIP(1, dim3((unsigned)nb_stats), dim3(256), strip_smem(1), s, p);
   hipLaunchKernelGGL(contrast_combine_kernel<1>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
   LAUNCH_STRIP(2, dim3((unsigned)nb_stats), dim3(256), strip_smem(2), s, p);

@@ -70,10 +70,12 @@ def main():
             return out
         return inner
 
-    skip = {"require_device", "out_size", "out_size_d", "krsc", "geom_fwd", "geoms_dgrad", "geom_stem", "geom_stem_fwd"}
+    skip = {"require_device", "out_size", "out_size_d", "krsc", "geom_fwd", "geoms_dgrad", "geom_stem", "geom_stem_fwd",
+            "seg_loss_fused_ok"}
     for name in dir(ops):
         fn = getattr(ops, name)
-        if name.startswith("_") or name in skip or not callable(fn) or getattr(fn, "__module__", "") != ops.__name__:
+        if name.startswith("_") or name in skip or not callable(fn) or isinstance(fn, type) or \
+                getattr(fn, "__module__", "") != ops.__name__:
             continue
         setattr(ops, name, wrap(name, fn))
 
