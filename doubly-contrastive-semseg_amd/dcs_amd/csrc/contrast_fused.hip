@@ -424,7 +424,6 @@ void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, con
 // FLOPs: 3 x 0.5 + 2 units of A^2 C 2 (one unit = 6.06 GFLOP at A = 4864, C = 128) against 3 algorithmic units.
 constexpr int TB = 64;                 // tile edge
 constexpr int XLDL = 132;              // LDS row stride of the X_J tile: 128 + 4 (odd number of 16-B slots: conflict-free b128 reads)
-constexpr int GLDL = 68;               // LDS row stride of the Gsym tile
 
 struct StripParams {
   const float* X; int ldx; const float* y; int ldy; const float* mask; int mb;
@@ -460,6 +459,51 @@ __device__ __forceinline__ float xlane32(const float (&v)[16], const int l31) {
   return op(x, __shfl_xor(x, 1, 64));
 }
 
+// Per-row constants of the strip kernels' epilogues ("fast record", 8 floats in LDS), derived once per staged row from
+// the row record {m, -, rn, den, 1/cnt, q, <dL,L>, clamp} so that one similarity element costs ~15 VALU instructions per
+// direction (the straightforward form measured 146 per element pair: branches around both exponentials, divisions,
+// five LDS reads per call):
+//   [0] a2 = it rn log2(e)   [1] b2 = -m rn log2(e)      L log2(e) = fma(S, a2, b2),  E = v_exp_f32 of that
+//   [2] k  = rn it / A_v (0 for a padding row: its gradient vanishes)          [3] den
+//   [4] cp = den / cnt (mode 0) | 1 / cnt (mode 1)     [5] cn = q / cnt (mode 0) | 1 / den (mode 1)
+//   [6] dot = <dL, L> (0 when the norm was clamped: no projection)             [7] y (label; < 0 = padding)
+// phase 1 only needs [7] and the reference shift, kept in [0].
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <int PHASE, int MODE>
+__device__ __forceinline__ void make_fast(float* __restrict__ dst, const float* __restrict__ rec, const float y, const float rnorm,
+                                          const float it, const float inv_av, const bool live) {
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+  if (PHASE == 1) a.x = rnorm;
+  if (PHASE >= 2 && live) {
+    const float4 r0 = ldg4(rec), r1 = ldg4(rec + 4);           // {m, -, rn, den}, {1/cnt, q, dot, clamp}
+    const float rn = r0.z;
+    a.x = it * rn * LOG2E; a.y = -r0.x * rn * LOG2E; a.z = rn * it * inv_av; a.w = r0.w;
+    if (MODE == 0) { b.x = r0.w * r1.x; b.y = r1.y * r1.x; } else { b.x = r1.x; b.y = 1.f / r0.w; }
+    b.z = r1.w != 0.f ? 0.f : r1.z;
+  }
+  b.w = live ? y : -1.f;
+  *reinterpret_cast<float4*>(dst) = a;
+  *reinterpret_cast<float4*>(dst + 4) = b;
+}
+
+// d loss / d S_ab * A_v-normalised, from the fast record R of row a.  pos = b is a positive of a (same label, not self),
+// w = its weight (mode 1), self = (a == b).  Branch-free.
+template <int MODE>
+__device__ __forceinline__ float g_fast(const float s, const float (&R)[8], const bool same, const bool self, const float w) {
+  const float L2 = fmaf(s, R[0], R[1]);
+  const float E = exp2_fast(L2);
+  const float L = L2 * LN2;
+  float dL;
+  if (MODE == 0) {
+    const float dp = -R[4] * rcp_fast(E + R[3]);
+    dL = same ? dp : E * R[5];
+  } else dL = fmaf(E, R[5], -w * R[4]);
+  dL = self ? 0.f : dL;
+  return fmaf(-L, R[6], dL) * R[2];
+}
+
 template <int PHASE, int MODE>
 __global__ __launch_bounds__(256, 2)
 void contrast_strip_kernel(const StripParams p) {
@@ -475,15 +519,12 @@ void contrast_strip_kernel(const StripParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* XJ = reinterpret_cast<float*>(smem_raw);                 // [64][XLDL]
   float* XI = XJ + TB * XLDL;                                     // [64][XLDL] (ALDS only)
-  float* recI = XI + (ALDS ? TB * XLDL : 0);                      // [64][REC]   (+ yI, rI in slots of their own)
-  float* recJ = recI + TB * REC;                                  // [64][REC]
-  float* auxI = recJ + TB * REC;                                  // [64][2] = y_i, r_i
-  float* auxJ = auxI + TB * 2;                                    // [64][2]
-  float* red = auxJ + TB * 2;                                     // [2][64][4] cross-wave reduction scratch
+  float* frI = XI + (ALDS ? TB * XLDL : 0);                       // [64][8] fast records of the strip rows
+  float* frJ = frI + TB * 8;                                      // [64][8] fast records of the streamed tile's rows
+  float* red = frJ + TB * 8;                                      // [2][64][4] cross-wave reduction scratch
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int A = p.A, C = p.C;
-  constexpr int mode = MODE;
   const float it = p.it;
 
   // block -> (strip I, first tile jbeg, end tile jend)
@@ -505,14 +546,12 @@ void contrast_strip_kernel(const StripParams p) {
   const float inv_av = PHASE == 4 ? 1.f / p.av[0] : 0.f;
 
   // strip-resident row data
-  for (int e = tid; e < TB * REC; e += 256) {
-    const int r = i0 + e / REC;
-    recI[e] = (PHASE >= 2 && r < A) ? p.rec[(long long)i0 * REC + e] : 0.f;
-  }
   if (tid < TB) {
     const int r = i0 + tid;
-    auxI[2 * tid] = r < A ? p.y[(long long)r * p.ldy] : -1.f;
-    auxI[2 * tid + 1] = r < A ? p.rnorm[r] : 0.f;
+    const bool in = r < A;
+    const float yv = in ? p.y[(long long)r * p.ldy] : -1.f;
+    make_fast<PHASE, MODE>(frI + tid * 8, p.rec + (long long)(in ? r : 0) * REC, yv, in ? p.rnorm[r] : 0.f, it, inv_av,
+                           in && yv >= 0.f);
   }
   // A operand: lane (r = l31, h) holds X_I[32 wm + l31][8 g + 4 h .. +3] for the 16 k8-groups of a 128-channel chunk
   const int rowA = i0 + 32 * wm + l31 < A ? i0 + 32 * wm + l31 : -1;
@@ -559,16 +598,16 @@ void contrast_strip_kernel(const StripParams p) {
   // software pipeline: the registers `st` hold the NEXT tile (issued right after the previous one was written to LDS),
   // so its L2 / HBM latency is covered by this tile's MFMAs and epilogue
   load_j(jbeg, 0, true);
-  // the tile's row records / labels / shifts ride the same pipeline: 2 + 2 floats per thread
-  float pr0 = 0.f, pr1 = 0.f, pa0 = -1.f, pa1 = 0.f;
+  // the tile's row records ride the same pipeline: threads 0..63 hold the next tile's fast record of one row
+  float4 pf0 = make_float4(0.f, 0.f, 0.f, 0.f), pf1 = make_float4(0.f, 0.f, 0.f, -1.f);
   auto load_aux = [&](int T, bool valid) {
-    const int r0 = T * TB + tid / REC, r1 = T * TB + (tid + 256) / REC;
-    pr0 = (PHASE >= 2 && valid && r0 < A) ? p.rec[(long long)T * TB * REC + tid] : 0.f;
-    pr1 = (PHASE >= 2 && valid && r1 < A) ? p.rec[(long long)T * TB * REC + tid + 256] : 0.f;
     if (tid < TB) {
       const int r = T * TB + tid;
-      pa0 = (valid && r < A) ? p.y[(long long)r * p.ldy] : -1.f;
-      pa1 = (valid && r < A) ? p.rnorm[r] : 0.f;
+      const bool in = valid && r < A;
+      const float yv = in ? p.y[(long long)r * p.ldy] : -1.f;
+      float tmp[8];
+      make_fast<PHASE, MODE>(tmp, p.rec + (long long)(in ? r : 0) * REC, yv, in ? p.rnorm[r] : 0.f, it, inv_av, in && yv >= 0.f);
+      pf0 = make_float4(tmp[0], tmp[1], tmp[2], tmp[3]); pf1 = make_float4(tmp[4], tmp[5], tmp[6], tmp[7]);
     }
   };
   load_aux(jbeg, true);
@@ -579,9 +618,9 @@ void contrast_strip_kernel(const StripParams p) {
     for (int kc = 0; kc < nkc; ++kc) {
       __syncthreads();                                             // readers of the previous XJ image are done
       store_j(XJ);
-      if (kc == 0) {
-        recJ[tid] = pr0; recJ[tid + 256] = pr1;
-        if (tid < TB) { auxJ[2 * tid] = pa0; auxJ[2 * tid + 1] = pa1; }
+      if (kc == 0 && tid < TB) {
+        *reinterpret_cast<float4*>(frJ + tid * 8) = pf0;
+        *reinterpret_cast<float4*>(frJ + tid * 8 + 4) = pf1;
       }
       if (nkc > 1) {
         if (ALDS) { load_j(I, kc, true); store_j(XI); } else load_a(kc);
@@ -606,122 +645,108 @@ void contrast_strip_kernel(const StripParams p) {
       }
     }
     if (p.dbg & 2) continue;
-    // ---- epilogue: lane holds S[i = 32 wm + row32(r, h)][j = 32 wn + l31], r = 0..15 ----
+    // ---- epilogue: lane holds S[i = 32 wm + row32(r, h)][j = 32 wn + l31], r = 0..15 (phase 4: [t][q]) ----
     const int jl = 32 * wn + l31, jg = J * TB + jl;
-    const float yj = auxJ[2 * jl], rj = auxJ[2 * jl + 1];
     const bool diag = J == I;
+    float Rl[8];                                                   // fast record of the lane's own row (tile row j / strip row q)
+    {
+      const float* src = (PHASE == 4 ? frI : frJ) + jl * 8;
+      const float4 u = *reinterpret_cast<const float4*>(src), v = *reinterpret_cast<const float4*>(src + 4);
+      Rl[0] = u.x; Rl[1] = u.y; Rl[2] = u.z; Rl[3] = u.w; Rl[4] = v.x; Rl[5] = v.y; Rl[6] = v.z; Rl[7] = v.w;
+    }
+    const float* frR = PHASE == 4 ? frJ : frI;                     // records of the rows held in the registers
+    const float yl = Rl[7];
+    auto col_out = [&](float c0, float c1, float c2, float c3, bool maxfirst) {
+      // column-direction results of this tile -> P[I][tile rows j]: the two lane halves, then the two wm waves
+      c0 = maxfirst ? fmaxf(c0, __shfl_xor(c0, 32, 64)) : c0 + __shfl_xor(c0, 32, 64);
+      c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64); c3 += __shfl_xor(c3, 32, 64);
+      if (h == 0) { float* q = &red[(wm * TB + jl) * 4]; q[0] = c0; q[1] = c1; q[2] = c2; q[3] = c3; }
+      __syncthreads();
+      if (tid < TB && J * TB + tid < A) {
+        const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
+        float* o = p.P + ((long long)I * A + J * TB + tid) * 4;
+        o[0] = maxfirst ? fmaxf(q0[0], q1[0]) : q0[0] + q1[0];
+        o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = q0[3] + q1[3];
+      }
+    };
     if (PHASE == 1) {
       float c0 = -3.0e38f, c1 = 0.f, c2 = 0.f;                     // column direction: statistics of row j over the rows i
+      const float rj = Rl[0];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int il = 32 * wm + row32(r, h);
-        const float yi = auxI[2 * il], ri = auxI[2 * il + 1];
+        const float* Rr = frR + (32 * wm + row32(r, h)) * 8;
+        const float yi = Rr[7], ri = Rr[0];
         const float v = acc[r] * it;
-        if (yi >= 0.f && yj >= 0.f) {
+        if (yi >= 0.f && yl >= 0.f) {
           const float d = v - ri;
           ra0[r] = fmaxf(ra0[r], v); ra1[r] += d; ra2[r] = fmaf(d, d, ra2[r]);
           if (!diag) { const float e = v - rj; c0 = fmaxf(c0, v); c1 += e; c2 = fmaf(e, e, c2); }
         }
       }
-      if (!diag) {                                                 // uniform per block
-        c0 = fmaxf(c0, __shfl_xor(c0, 32, 64)); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
-        if (h == 0) { float* q = &red[(wm * TB + jl) * 4]; q[0] = c0; q[1] = c1; q[2] = c2; q[3] = 0.f; }
-        __syncthreads();
-        if (tid < TB && J * TB + tid < A) {
-          const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
-          float* o = p.P + ((long long)I * A + J * TB + tid) * 4;
-          o[0] = fmaxf(q0[0], q1[0]); o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = 0.f;
-        }
-      }
+      if (!diag) col_out(c0, c1, c2, 0.f, true);                   // uniform per block
     } else if (PHASE == 2) {
       float c0 = 0.f, c1 = 0.f, c2 = 0.f, c3 = 0.f;
-      const float mj = recJ[jl * REC], rnj = recJ[jl * REC + 2];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int il = 32 * wm + row32(r, h), ig = i0 + il;
-        const float yi = auxI[2 * il];
-        if (yi < 0.f || yj < 0.f) continue;
-        const float v = acc[r] * it;
-        const bool same = yi == yj, self = ig == jg;
-        {                                                          // row i, column j
-          const float L = (v - recI[il * REC]) * recI[il * REC + 2];
-          const float E = exp_unit(L);
-          if (mode == 0) { if (!same) { ra0[r] += E; ra2[r] = fmaf(E, L, ra2[r]); } else if (!self) ra1[r] += 1.f; }
-          else if (!self) {
-            const float w = pos_weight(p.mask, p.mb, ig, jg, yi, yj);
-            ra0[r] += E; ra2[r] = fmaf(E, L, ra2[r]); ra1[r] += w; if (HAS3) ra3[r] = fmaf(w, L, ra3[r]);
-          }
-        }
-        if (!diag) {                                               // row j, column i (S_ji = S_ij)
-          const float L = (v - mj) * rnj;
-          const float E = exp_unit(L);
-          if (mode == 0) { if (!same) { c0 += E; c2 = fmaf(E, L, c2); } else c1 += 1.f; }
-          else {
-            const float w = pos_weight(p.mask, p.mb, jg, ig, yj, yi);
-            c0 += E; c2 = fmaf(E, L, c2); c1 += w; c3 = fmaf(w, L, c3);
-          }
+        const float* Rr = frR + il * 8;
+        const float4 u = *reinterpret_cast<const float4*>(Rr);
+        const float yi = Rr[7];
+        const float s_ = acc[r];
+        const bool valid = yi >= 0.f && yl >= 0.f, same = yi == yl, self = ig == jg;
+        // row i, column j: E = exp(L_ij) with row i's shift / norm; branch-free 0/1 weights
+        const float L2i = fmaf(s_, u.x, u.y), Ei = exp2_fast(L2i), Li = L2i * LN2;
+        const float L2j = fmaf(s_, Rl[0], Rl[1]), Ej = exp2_fast(L2j), Lj = L2j * LN2;
+        if (MODE == 0) {
+          const float neg = (valid && !same) ? 1.f : 0.f, pos = (valid && same && !self) ? 1.f : 0.f;
+          ra0[r] = fmaf(neg, Ei, ra0[r]); ra2[r] = fmaf(neg * Ei, Li, ra2[r]); ra1[r] += pos;
+          if (!diag) { c0 = fmaf(neg, Ej, c0); c2 = fmaf(neg * Ej, Lj, c2); c1 += pos; }
+        } else {
+          const float off = (valid && !self) ? 1.f : 0.f;
+          const float wi = off * pos_weight(p.mask, p.mb, ig, jg, yi, yl), wj = off * pos_weight(p.mask, p.mb, jg, ig, yl, yi);
+          ra0[r] = fmaf(off, Ei, ra0[r]); ra2[r] = fmaf(off * Ei, Li, ra2[r]); ra1[r] += wi; if (HAS3) ra3[r] = fmaf(wi, Li, ra3[r]);
+          if (!diag) { c0 = fmaf(off, Ej, c0); c2 = fmaf(off * Ej, Lj, c2); c1 += wj; c3 = fmaf(wj, Lj, c3); }
         }
       }
-      if (!diag) {
-        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64); c3 += __shfl_xor(c3, 32, 64);
-        if (h == 0) { float* q = &red[(wm * TB + jl) * 4]; q[0] = c0; q[1] = c1; q[2] = c2; q[3] = c3; }
-        __syncthreads();
-        if (tid < TB && J * TB + tid < A) {
-          const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
-          float* o = p.P + ((long long)I * A + J * TB + tid) * 4;
-          o[0] = q0[0] + q1[0]; o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = q0[3] + q1[3];
-        }
-      }
+      if (!diag) col_out(c0, c1, c2, c3, false);
     } else if (PHASE == 3) {
       float c0 = 0.f, c1 = 0.f, c2 = 0.f;
-      const float mj = recJ[jl * REC], rnj = recJ[jl * REC + 2], denj = recJ[jl * REC + 3];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int il = 32 * wm + row32(r, h), ig = i0 + il;
-        const float yi = auxI[2 * il];
-        if (yi < 0.f || yi != yj || ig == jg) continue;            // positives only
-        const float v = acc[r] * it;
+        const float* Rr = frR + il * 8;
+        const float4 u = *reinterpret_cast<const float4*>(Rr);
+        const float yi = Rr[7];
+        if (yi < 0.f || yi != yl || ig == jg) continue;            // positives only (~1/19 of the pairs: branch, no select)
+        const float s_ = acc[r];
         {
-          const float den = recI[il * REC + 3];
-          const float L = (v - recI[il * REC]) * recI[il * REC + 2];
-          const float d = exp_unit(L) + den, id = rcp_fast(d);
+          const float L2 = fmaf(s_, u.x, u.y), L = L2 * LN2, den = u.w;
+          const float d = exp2_fast(L2) + den, id = rcp_fast(d);
           ra0[r] += L - __logf(d); ra1[r] += id; ra2[r] = fmaf(den * id, L, ra2[r]);
         }
         if (!diag) {
-          const float L = (v - mj) * rnj;
-          const float d = exp_unit(L) + denj, id = rcp_fast(d);
-          c0 += L - __logf(d); c1 += id; c2 = fmaf(denj * id, L, c2);
+          const float L2 = fmaf(s_, Rl[0], Rl[1]), L = L2 * LN2, den = Rl[3];
+          const float d = exp2_fast(L2) + den, id = rcp_fast(d);
+          c0 += L - __logf(d); c1 += id; c2 = fmaf(den * id, L, c2);
         }
       }
-      if (!diag) {
-        c0 += __shfl_xor(c0, 32, 64); c1 += __shfl_xor(c1, 32, 64); c2 += __shfl_xor(c2, 32, 64);
-        if (h == 0) { float* q = &red[(wm * TB + jl) * 4]; q[0] = c0; q[1] = c1; q[2] = c2; q[3] = 0.f; }
-        __syncthreads();
-        if (tid < TB && J * TB + tid < A) {
-          const float* q0 = &red[tid * 4]; const float* q1 = &red[(TB + tid) * 4];
-          float* o = p.P + ((long long)I * A + J * TB + tid) * 4;
-          o[0] = q0[0] + q1[0]; o[1] = q0[1] + q1[1]; o[2] = q0[2] + q1[2]; o[3] = 0.f;
-        }
-      }
+      if (!diag) col_out(c0, c1, c2, 0.f, false);
     } else {
       // PHASE 4 (roles swapped, see above): lane = strip row q, registers = tile rows t
-      const int ql = 32 * wn + l31, qg = i0 + ql;
-      const float yq = auxI[2 * ql];
-      float rq[REC];
-#pragma unroll
-      for (int e = 0; e < REC; ++e) rq[e] = recI[ql * REC + e];
+      const int qg = i0 + jl;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int tl = 32 * wm + row32(r, h), tg = J * TB + tl;
-        const float yt = auxJ[2 * tl];
-        float gs = 0.f;
-        if (yq >= 0.f && yt >= 0.f) {
-          const bool same = yq == yt, self = qg == tg;
-          const float wqt = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, qg, tg, yq, yt) : 0.f;
-          const float wtq = (mode == 1 && !self) ? pos_weight(p.mask, p.mb, tg, qg, yt, yq) : 0.f;
-          gs = (g_entry<float>(acc[r], rq, it, it, mode, same, self, wqt) +
-                g_entry<float>(acc[r], recJ + tl * REC, it, it, mode, same, self, wtq)) * inv_av;
-        }
+        const float* Rr = frR + tl * 8;
+        const float4 u = *reinterpret_cast<const float4*>(Rr), v = *reinterpret_cast<const float4*>(Rr + 4);
+        const float Rt[8] = {u.x, u.y, u.z, u.w, v.x, v.y, v.z, v.w};
+        const float yt = v.w;
+        const bool same = yl == yt, self = qg == tg;
+        const float wqt = MODE == 1 ? pos_weight(p.mask, p.mb, qg, tg, yl, yt) : 0.f;
+        const float wtq = MODE == 1 ? pos_weight(p.mask, p.mb, tg, qg, yt, yl) : 0.f;
+        // a padding row has k = 0 in its own record; the partner's term must vanish too
+        const float vmask = (yl >= 0.f && yt >= 0.f) ? 1.f : 0.f;
+        const float gs = (g_fast<MODE>(acc[r], Rl, same, self, wqt) + g_fast<MODE>(acc[r], Rt, same, self, wtq)) * vmask;
         if (p.gsym) { if (qg < A && tg < A) p.gsym[(long long)qg * p.ldg + tg] = gs; }
         acc[r] = gs;
       }
@@ -893,7 +918,7 @@ void contrast_finish_kernel(const float* __restrict__ slab, int nchunk, long lon
 
 size_t strip_smem(int phase) {
   (void)phase;
-  return (size_t)(2 * TB * XLDL + 2 * TB * REC + 4 * TB + 2 * TB * 4) * sizeof(float);
+  return (size_t)(2 * TB * XLDL + 2 * TB * 8 + 2 * TB * 4) * sizeof(float);
 }
 
 int large_ws_floats(int A, int C, int64_t* out) {

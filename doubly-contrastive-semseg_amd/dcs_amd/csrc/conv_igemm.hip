@@ -38,12 +38,21 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
   return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
+// BatchNorm-backward sums in a data-gradient epilogue (see conv_epilogue): y = the input of the BatchNorm whose
+// output gradient this launch produces (same [M][dst_cstride] layout as dst), mask = the tensor whose sign is the ReLU
+// mask (nullable), bn = [scale, shift, mean, invstd] x C record, relu = derive the mask from y*scale+shift.
+struct BnBwdEpi { const float* y; const float* mask; const float* bn; int relu; };
+
 // Epilogue shared by the convolution kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5).  Each wave transposes its accumulators 32 rows at a time through a private
 // LDS tile and writes 16 B per lane (a quarter wave covers one contiguous run of the pixel's channels) instead of
 // 4-byte column-strided stores.  With `stats`, the per-channel sum and sum of squares of this block's outputs (the
 // BatchNorm batch statistics of the layer that follows) are reduced in fixed order and written to
 // stats[128-pixel row][2][Cout], so the activation is not read again by a separate reduction pass.
+// With `bnb.y` (data-gradient launches), stats instead receives, per 128-pixel row, sum(gm) and sum(gm * xhat) with
+// gm = (final dst value) * ReLU mask, xhat = (y - mean) * invstd: the two reductions of the BatchNorm backward that
+// consumes this gradient, taken while the values are in registers (network/backbone/resnet_pyramid.py:28-36,:71-89
+// backward; the separate reduction pass -- 2 of the 5 tensor passes of a BatchNorm backward -- disappears).
 // smem: the block's LDS (free after the main loop's final barrier); rowoff[BM]: element offset of every tile row in
 // dst, or -1; wave (wm, wn) owns rows wm*TM*32.. and columns wn*TN*32.. of the tile.
 template <int BM, int BN, int TM, int TN, int WM, int SMEM_FLOATS>
@@ -51,7 +60,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
                                               const float* __restrict__ bias, float* __restrict__ dst,
                                               const int dst_cstride, const int Cout, const int co0, const int accumulate,
                                               float* __restrict__ stats, const long long mtile,
-                                              const unsigned long long M, const int wm, const int wn) {
+                                              const unsigned long long M, const int wm, const int wn,
+                                              const BnBwdEpi bnb = BnBwdEpi{nullptr, nullptr, nullptr, 0}) {
   constexpr int EPC = TN * 32;            // columns of a wave's sub-tile
   constexpr int EPL = EPC + 4;            // staging row stride (16-B aligned rows, conflict-free column writes)
   constexpr int EPV = EPC / 4;            // float4 per staged row
@@ -64,6 +74,16 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
   float ssum[TN], ssq[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) { ssum[b] = 0.f; ssq[b] = 0.f; }
+  // BatchNorm-backward sums: this lane's four channels colv .. colv+3 over its rows
+  float4 b_s0 = zero4(), b_s1 = zero4(), b_sc = zero4(), b_sh = zero4(), b_mu = zero4(), b_is = zero4();
+  const bool do_bnb = bnb.y != nullptr;
+  {
+    const int colv0 = co0 + wn * EPC + (lane % EPV) * 4;
+    if (do_bnb && colv0 + 3 < Cout) {
+      b_sc = ld4(bnb.bn + colv0); b_sh = ld4(bnb.bn + Cout + colv0);
+      b_mu = ld4(bnb.bn + 2 * Cout + colv0); b_is = ld4(bnb.bn + 3 * Cout + colv0);
+    }
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a) {
     const int row0 = wm * TM * 32 + a * 32;
@@ -76,7 +96,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
         const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[a][b][r] + bvv;
         stg[rl * EPL + b * 32 + l31] = v;
-        if (stats && rowoff[row0 + rl] >= 0) { ssum[b] += v; ssq[b] = fmaf(v, v, ssq[b]); }
+        if (stats && !do_bnb && rowoff[row0 + rl] >= 0) { ssum[b] += v; ssq[b] = fmaf(v, v, ssq[b]); }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -93,6 +113,20 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
       if (vec_ok && colv + 3 < Cout) {
         if (accumulate) { const float4 o = ld4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         *reinterpret_cast<float4*>(q) = v;
+        if (do_bnb) {
+          const float4 yy = ld4(bnb.y + ro + colv);
+          float4 gm = v;
+          if (bnb.mask) {
+            const float4 ms = ld4(bnb.mask + ro + colv);
+            gm.x = ms.x > 0.f ? gm.x : 0.f; gm.y = ms.y > 0.f ? gm.y : 0.f; gm.z = ms.z > 0.f ? gm.z : 0.f; gm.w = ms.w > 0.f ? gm.w : 0.f;
+          } else if (bnb.relu) {
+            gm.x = fmaf(yy.x, b_sc.x, b_sh.x) > 0.f ? gm.x : 0.f; gm.y = fmaf(yy.y, b_sc.y, b_sh.y) > 0.f ? gm.y : 0.f;
+            gm.z = fmaf(yy.z, b_sc.z, b_sh.z) > 0.f ? gm.z : 0.f; gm.w = fmaf(yy.w, b_sc.w, b_sh.w) > 0.f ? gm.w : 0.f;
+          }
+          b_s0.x += gm.x; b_s0.y += gm.y; b_s0.z += gm.z; b_s0.w += gm.w;
+          b_s1.x = fmaf(gm.x, (yy.x - b_mu.x) * b_is.x, b_s1.x); b_s1.y = fmaf(gm.y, (yy.y - b_mu.y) * b_is.y, b_s1.y);
+          b_s1.z = fmaf(gm.z, (yy.z - b_mu.z) * b_is.z, b_s1.z); b_s1.w = fmaf(gm.w, (yy.w - b_mu.w) * b_is.w, b_s1.w);
+        }
       } else {
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -104,13 +138,27 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
     __builtin_amdgcn_wave_barrier();
   }
   if (stats) {
+    if (do_bnb) {
+      // lanes with the same channel group (lane % EPV) hold different rows: fixed-order butterfly over lane / EPV
+      float vals[8] = {b_s0.x, b_s0.y, b_s0.z, b_s0.w, b_s1.x, b_s1.y, b_s1.z, b_s1.w};
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int cl = wn * EPC + b * 32 + l31;
-      float s0 = ssum[b], s1 = ssq[b];
-      s0 += __shfl_xor(s0, 32, 64);
-      s1 += __shfl_xor(s1, 32, 64);
-      if (h == 0) { st[(wm * BN + cl) * 2] = s0; st[(wm * BN + cl) * 2 + 1] = s1; }
+      for (int o = EPV; o < 64; o <<= 1)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vals[e] += __shfl_xor(vals[e], o, 64);
+      if (lane < EPV) {
+        const int cl = wn * EPC + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { st[(wm * BN + cl + e) * 2] = vals[e]; st[(wm * BN + cl + e) * 2 + 1] = vals[4 + e]; }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int cl = wn * EPC + b * 32 + l31;
+        float s0 = ssum[b], s1 = ssq[b];
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if (h == 0) { st[(wm * BN + cl) * 2] = s0; st[(wm * BN + cl) * 2 + 1] = s1; }
+      }
     }
     __syncthreads();
     // one statistics row per 128 output pixels, whatever BM is (the host sizes the buffer for 128-pixel rows)
@@ -136,7 +184,7 @@ __global__ __launch_bounds__(256, (BKT == 16 && BM * BN <= 128 * 128) ? 3 : 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                         const float* __restrict__ bias, float* __restrict__ dst,
                         const DcsConvGeom g, const int accumulate, const int ntiles, float* __restrict__ stats,
-                        const int cps, const long long slab_stride) {
+                        const int cps, const long long slab_stride, const BnBwdEpi bnb) {
   constexpr int WN = (BN >= 128 || (BN == 64 && BM == 128)) ? 2 : 1;
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (WM * 32);
@@ -328,7 +376,7 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   }
 
   conv_epilogue<BM, BN, TM, TN, WM, 2 * (BM + BN) * LDKT>(acc, smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0,
-                                                          accumulate, stats, mtile, M, wm, wn);
+                                                          accumulate, stats, mtile, M, wm, wn, bnb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -892,7 +940,8 @@ static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
 // 3x3 kernel with the 6x34-pixel input halo resident in LDS (3-5 % slower than this per-tap kernel).
 
 static int launch_gather(const float* src, const float* wgt, const float* bias, float* dst, const DcsConvGeom* geom,
-                         int accumulate, float* stats, int nsplit, long long slab_stride, void* stream) {
+                         int accumulate, float* stats, int nsplit, long long slab_stride, void* stream,
+                         const BnBwdEpi bnb = BnBwdEpi{nullptr, nullptr, nullptr, 0}) {
   int rc = check_geom(geom);
   if (rc != DCS_OK) return rc;
   DCS_CHECK_ARG(src && wgt && dst && dcs_aligned16(src) && dcs_aligned16(wgt));
@@ -913,7 +962,10 @@ static int launch_gather(const float* src, const float* wgt, const float* bias, 
   }
   const int bn = geom->Cout > 64 ? 128 : (geom->Cout > 32 ? 64 : 32);
   const int ntiles = (geom->Cout + bn - 1) / bn;
-  DCS_CHECK_ARG(!(stats && accumulate));
+  DCS_CHECK_ARG(!(stats && accumulate && !bnb.y));
+  // BatchNorm-backward sums: dense vectorised destination, y (and mask) share its layout
+  DCS_CHECK_ARG(!bnb.y || (stats && bnb.bn && nsplit == 1 && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
+                           dcs_aligned16(dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
   // few K chunks per tile (1x1 convolutions up to 512 channels): 16-channel chunks, 3 blocks per CU, so that the
   // prologue / epilogue of one tile overlaps the main loop of two others (measured +14..18 % on those shapes)
   const bool short_k = (long long)geom->ntaps * ((geom->K + 31) / 32) <= 16;
@@ -928,7 +980,7 @@ static int launch_gather(const float* src, const float* wgt, const float* bias, 
   hipStream_t s = dcs_stream(stream);
 #define LAUNCH_K(...)                                                                                                  \
   hipLaunchKernelGGL((conv_gather_kernel<__VA_ARGS__>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, \
-                     wgt, bias, dst, *geom, accumulate, ntiles, stats, cps, slab_stride)
+                     wgt, bias, dst, *geom, accumulate, ntiles, stats, cps, slab_stride, bnb)
   if (geom->stem) {
     // 14-tap stem geometry = half filter rows of 4 pixels (16 floats): 16-float chunks, 32.5 KB LDS, more blocks per CU
     if (stem14) LAUNCH_K(64, true, 16);
@@ -950,6 +1002,13 @@ static int launch_gather(const float* src, const float* wgt, const float* bias, 
 extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
                                const DcsConvGeom* geom, int accumulate, float* stats, void* stream) {
   return launch_gather(src, wgt, bias, dst, geom, accumulate, stats, 1, 0, stream);
+}
+
+extern "C" int dcs_conv_gather_bnbwd(const float* src, const float* wgt, float* dst, const DcsConvGeom* geom, int accumulate,
+                                     const float* bn_y, const float* bn_mask, const float* bn, int relu, float* part,
+                                     void* stream) {
+  DCS_CHECK_ARG(bn_y && bn && part);
+  return launch_gather(src, wgt, nullptr, dst, geom, accumulate, part, 1, 0, stream, BnBwdEpi{bn_y, bn_mask, bn, relu});
 }
 
 extern "C" int dcs_conv_gather_split(const float* src, const float* wgt, float* slab, const DcsConvGeom* geom, int nsplit,

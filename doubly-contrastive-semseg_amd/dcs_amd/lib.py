@@ -31,6 +31,7 @@ _G = C.POINTER(DcsConvGeom)
 # name -> argtypes (all return int); mirrors include/dcs_hip.h one to one
 SIGNATURES = {
     "dcs_conv_gather": [_P, _P, _P, _P, _G, _I, _P, _P],
+    "dcs_conv_gather_bnbwd": [_P, _P, _P, _G, _I, _P, _P, _P, _I, _P, _P],
     "dcs_conv_gather_split": [_P, _P, _P, C.POINTER(DcsConvGeom), _I, _L, _P],
     "dcs_conv_wgrad": [_P, _P, _P, _G, _I, _I, _I, _P],
     "dcs_reduce_slab": [_P, _P, _L, _I, _I, _I, _I, _P],

@@ -372,13 +372,18 @@ class SwiftNetEngine:
                 grads[seg.conv.bias].copy_(bsum[0, 0, :self.num_classes])
                 wpad = torch.zeros((NUM_FEATURES, 1, 1, LOGIT_CS), device=gb.device, dtype=gb.dtype)
                 wpad[..., :self.num_classes] = wp(seg.conv)
-                g_zh = ops.conv_dgrad(gb, wpad, (h, w), 1, 0)
+                # the data gradient's epilogue also reduces the sums of the BatchNorm backward that consumes it
+                ff0c = ff0 if ff0.is_contiguous() else None
+                if ff0c is not None:
+                    g_zh, hs = ops.conv_dgrad(gb, wpad, (h, w), 1, 0, bnb=(ff0c, None, bnh, True))
+                else:
+                    g_zh, hs = ops.conv_dgrad(gb, wpad, (h, w), 1, 0), None
                 if g_ff is None and saved.Bm == B:
-                    g_ff, _ = bn_bwd(seg.norm, g_zh, ff0, bnh, relu=True)
+                    g_ff, _ = bn_bwd(seg.norm, g_zh, ff0, bnh, relu=True, sums=hs)
                 else:
                     if g_ff is None:
                         g_ff = torch.zeros((saved.Bm, h, w, NUM_FEATURES), device=gb.device, dtype=gb.dtype)
-                    bn_bwd(seg.norm, g_zh, ff0, bnh, relu=True, dy_out=g_ff[:B], acc_dy=True)
+                    bn_bwd(seg.norm, g_zh, ff0, bnh, relu=True, dy_out=g_ff[:B], acc_dy=True, sums=hs)
         if g_ff is None:
             raise RuntimeError("backward called without any gradient")
         g_x = g_ff
@@ -387,14 +392,24 @@ class SwiftNetEngine:
             _, i, in_hw, t, bn, z, blend = tape[pos]
             pos -= 1
             wgrad(blend.conv, z, g_x, 1, 1)
-            g_z = ops.conv_dgrad(g_x, wp(blend.conv), t.shape[1:3], 1, 1)
-            g_t, _ = bn_bwd(blend.norm, g_z, t, bn, relu=True)
+            g_z, bs = ops.conv_dgrad(g_x, wp(blend.conv), t.shape[1:3], 1, 1, bnb=(t, None, bn, True))
+            g_t, _ = bn_bwd(blend.norm, g_z, t, bn, relu=True, sums=bs)
             g_skip[5 - i] = g_t                      # skips[idx + li] with idx + li = 5 - i
             g_x = ops.upsample_bwd(g_t, in_hw[0], in_hw[1])
         g_skip[5] = g_x                              # coarsest map: level 2, layer4
         # ---- encoder, pyramid levels in reverse creation order ----
         g_cur = None
+        cur_sums = None                # BatchNorm-backward sums of g_cur for the block that consumes it next (or None)
         dwst = None
+
+        def consumer_bnb():
+            """The next tape item, if it is a block: g_cur written now is final and goes into that block's bn2 backward
+            (mask = sign of the block output): its two sums can ride the epilogue of the kernel that writes g_cur last."""
+            if pos >= 0 and tape[pos][0] == "block":
+                _, _, _, _, _, _, y2n, bn2n, _, _, outn = tape[pos]
+                return (y2n, outn, bn2n, False)
+            return None
+
         while pos >= 0:
             item = tape[pos]
             pos -= 1
@@ -403,21 +418,25 @@ class SwiftNetEngine:
                 _, lvl, x, bott = item
                 gs = g_skip[lvl]
                 wgrad(bott, x, gs, 1, 0)
+                # the skip projection's data gradient is the LAST writer of the gradient of this layer's output
+                cb = consumer_bnb()
                 if g_cur is None:
-                    g_cur = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0)
+                    r = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, bnb=cb)
                 else:
-                    ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, out=g_cur, accumulate=True)
+                    r = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, out=g_cur, accumulate=True, bnb=cb)
+                g_cur, cur_sums = r if cb is not None else (r, None)
             elif kind == "block":
                 _, blk, x, y1, bn1, z1, y2, bn2, yd, bnd, out = item
                 s = blk.stride
-                dy2, gm = bn_bwd(blk.bn2, g_cur, y2, bn2, masksrc=out, want_gm=True)
+                dy2, gm = bn_bwd(blk.bn2, g_cur, y2, bn2, masksrc=out, want_gm=True, sums=cur_sums)
+                cur_sums = None
                 if training:       # activation-checkpoint recompute side effect
                     ops.bn_ema_again(bn2, blk.bn2.running_mean, blk.bn2.running_var, y2.numel() // y2.shape[-1],
                                      momentum=blk.bn2.momentum)
                     self._nbt.append(blk.bn2)
                 wgrad(blk.conv2, z1, dy2, 1, 1)
-                g_z1 = ops.conv_dgrad(dy2, wp(blk.conv2), z1.shape[1:3], 1, 1)
-                dy1, _ = bn_bwd(blk.bn1, g_z1, y1, bn1, relu=True)
+                g_z1, s1 = ops.conv_dgrad(dy2, wp(blk.conv2), z1.shape[1:3], 1, 1, bnb=(y1, None, bn1, True))
+                dy1, _ = bn_bwd(blk.bn1, g_z1, y1, bn1, relu=True, sums=s1)
                 if training:
                     ops.bn_ema_again(bn1, blk.bn1.running_mean, blk.bn1.running_var, y1.numel() // y1.shape[-1],
                                      momentum=blk.bn1.momentum)
@@ -429,8 +448,11 @@ class SwiftNetEngine:
                     g_in = ops.conv_dgrad(dyd, wp(blk.downsample[0]), x.shape[1:3], s, 0)
                 else:
                     g_in = gm
-                ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1, out=g_in, accumulate=True)
-                g_cur = g_in
+                # conv1's data gradient is the last writer of this block's input gradient unless a skip projection
+                # follows (first block of a layer: the next tape item is then "skip", not "block")
+                cb = consumer_bnb()
+                r = ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1, out=g_in, accumulate=True, bnb=cb)
+                g_cur, cur_sums = r if cb is not None else (r, None)
             elif kind == "stem":
                 _, idx, p, y, bn, pidx, bnm = item
                 acc = bnm.weight in grads

@@ -239,8 +239,13 @@ def pack_dgrad_weight(w, koff=0, kw=None):
     return o
 
 
-def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None, dil=1):
-    """Data gradient.  dy [N,OH,OW,cs>=Cout]; wp = pack_dgrad_weight(w) [Cin,R,S,Cout]."""
+def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None, dil=1, bnb=None):
+    """Data gradient.  dy [N,OH,OW,cs>=Cout]; wp = pack_dgrad_weight(w) [Cin,R,S,Cout].
+
+    bnb = (y, mask, bn, relu): the result is the gradient arriving at a BatchNorm (input y [N,IH,IW,Cin], record bn,
+    ReLU mask from ``mask > 0`` or, with relu, from the recomputed BatchNorm output): the epilogue also reduces the two
+    sums of that BatchNorm's backward; returns (out, sums [2,Cin]) -- sums is None when the launch cannot carry them
+    (split-K launches of tiny maps), the caller then lets bn_bwd take them in its own pass."""
     _req(dy)
     N = dy.shape[0]
     Cin, R, S, Cout = wp.shape
@@ -252,6 +257,34 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
     elif not accumulate and any(g is None for g in gs):
         out.zero_()
     cs = dy.shape[3]
+    fuse = bnb is not None and all(g is not None for g in gs) and out.is_contiguous() and Cin % 4 == 0
+    part = None
+    if fuse:
+        tiles = [-(-(N * g.TY * g.TX) // CONV_BM) for g in gs]
+        ns1 = _ksplit(gs[0], N * gs[0].TY * gs[0].TX, Cin) if len(gs) == 1 else 1
+        fuse = ns1 == 1
+    if fuse:
+        G = sum(tiles)
+        G1 = 0 if G <= 2048 else -(-G // 128)
+        part = (torch.empty((G, 2, Cin), device=dy.device, dtype=_F32) if G1 == 0 else
+                torch.zeros((G1 * 128, 2, Cin), device=dy.device, dtype=_F32))
+        yb, mb, bnr, relu = bnb
+        _req(yb)
+        off = 0
+        for g, t in zip(gs, tiles):
+            if cs != g.src_cstride:
+                g = _with_src_cs(g, cs)
+            _call("dcs_conv_gather_bnbwd", _p(dy), _p(wp), _p(out), C.byref(g), 1 if accumulate else 0, _p(yb), _p(mb), _p(bnr),
+                  1 if relu else 0, C.c_void_p(part.data_ptr() + off * 2 * Cin * 4), _stream())
+            off += t
+        sums = torch.empty((2, Cin), device=dy.device, dtype=_F32)
+        if G1 == 0:
+            _call("dcs_colsum_final", _p(part), _p(sums), 1, G, Cin, 1.0, 0.0, _stream())
+        else:
+            mid = torch.empty((G1, 2, Cin), device=dy.device, dtype=_F32)
+            _call("dcs_colsum_final", _p(part), _p(mid), G1, 128, Cin, 1.0, 0.0, _stream())
+            _call("dcs_colsum_final", _p(mid), _p(sums), 1, G1, Cin, 1.0, 0.0, _stream())
+        return out, sums
     for g in gs:
         if g is None:
             continue
@@ -262,7 +295,7 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
             _gather_split(dy, wp, g, ns, out, accumulate)
         else:
             _call("dcs_conv_gather", _p(dy), _p(wp), None, _p(out), C.byref(g), 1 if accumulate else 0, None, _stream())
-    return out
+    return (out, None) if bnb is not None else out
 
 
 def _with_src_cs(g, cs):
@@ -420,17 +453,19 @@ def bn_act(y, bn, r=None, bn2=None, relu=True):
 
 
 def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=False, dy_out=None, acc_dy=False,
-           dgamma=None, dbeta=None, acc_param=False, training=True):
-    """BatchNorm (+ReLU mask) backward.  Returns (dy, gm).  dgamma/dbeta are written (or accumulated)."""
+           dgamma=None, dbeta=None, acc_param=False, training=True, sums=None):
+    """BatchNorm (+ReLU mask) backward.  Returns (dy, gm).  dgamma/dbeta are written (or accumulated).
+    sums [2,C] = (sum gm, sum gm * xhat) when the kernel that produced g already reduced them (conv_dgrad(bnb=...))."""
     _req(g), _req(y)
     Cc = y.shape[-1]
     rows = y.numel() // Cc
-    grp = _groups(rows)
-    part = torch.empty((1, grp, 2, Cc), device=y.device, dtype=_F32)
-    _call("dcs_colsum_partial", _p(g), _p(y), _p(masksrc), _p(bn), _p(part), 1, rows, Cc, Cc, grp, 1,
-          1 if relu else 0, _stream())
-    sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
-    _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, 0.0, _stream())
+    if sums is None:
+        grp = _groups(rows)
+        part = torch.empty((1, grp, 2, Cc), device=y.device, dtype=_F32)
+        _call("dcs_colsum_partial", _p(g), _p(y), _p(masksrc), _p(bn), _p(part), 1, rows, Cc, Cc, grp, 1,
+              1 if relu else 0, _stream())
+        sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
+        _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, 0.0, _stream())
     dy = None
     if want_dy:
         dy = dy_out if dy_out is not None else torch.empty_like(y)

@@ -66,6 +66,15 @@ typedef struct DcsConvGeom {
 int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float* dst,
                     const DcsConvGeom* geom, int accumulate, float* stats, void* stream);
 
+/* Data gradient with the BatchNorm-backward reductions in its epilogue: as dcs_conv_gather (no bias), and part
+ * [ceil(M/DCS_CONV_BM)][2][Cout] receives per row tile sum(gm) and sum(gm * xhat), gm = (final dst value, after the
+ * optional accumulate) * ReLU mask, xhat = (bn_y - mean) * invstd -- the sums dcs_colsum_partial(mode 1) would take in a
+ * pass of its own.  bn_y (and bn_mask, nullable: mask = bn_mask > 0; else relu ? bn_y*scale+shift > 0 : 1) have dst's
+ * layout; dst must be dense (dst_cstride == Cout, Cout % 4 == 0).  Stride-2 data gradients are several launches (one
+ * per input parity class), each with its own rows of part; dcs_colsum_final sums them all. */
+int dcs_conv_gather_bnbwd(const float* src, const float* wgt, float* dst, const DcsConvGeom* geom, int accumulate,
+                          const float* bn_y, const float* bn_mask, const float* bn, int relu, float* part, void* stream);
+
 /* Split-K variant of dcs_conv_gather for launches with few output tiles (deep layers of small inputs: a handful of
  * blocks behind a 100+-chunk serial loop leaves most CUs idle): grid.y = nsplit, split s reduces its share of the
  * (tap, channel-chunk) range and writes its partial output to slab + s * slab_stride (same addressing as dst;

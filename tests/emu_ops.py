@@ -48,7 +48,7 @@ def pack_dgrad_weight(w, koff=0, kw=None):
     return w[:, koff:koff + kw].permute(1, 2, 3, 0).contiguous()          # [Cin,R,S,Cout]
 
 
-def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None, dil=1):
+def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=None, dil=1, bnb=None):
     Cin, R, S, Cout = wp.shape
     w = wp.permute(3, 0, 1, 2)[:, :, :, :]              # [Cout,Cin,R,S]
     N = dy.shape[0]
@@ -56,12 +56,24 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
                                    stride, pad, dil)
     g = _nhwc(g)
     if out is None:
-        return g
-    if accumulate:
+        out = g
+    elif accumulate:
         out.add_(g)
     else:
         out.copy_(g)
-    return out
+    if bnb is None:
+        return out
+    # contract of dcs_conv_gather_bnbwd: the BatchNorm-backward sums of the FINAL values, in double
+    y, mask, bn, relu = bnb
+    gm = out
+    if mask is not None:
+        gm = out * (mask > 0)
+    elif relu:
+        gm = out * ((y * bn[0] + bn[1]) > 0)
+    xhat = (y - bn[2]) * bn[3]
+    s0 = gm.reshape(-1, Cin).double().sum(0).to(y.dtype)
+    s1 = (gm * xhat).reshape(-1, Cin).double().sum(0).to(y.dtype)
+    return out, torch.stack([s0, s1])
 
 
 def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
@@ -169,7 +181,7 @@ def bn_act(y, bn, r=None, bn2=None, relu=True):
 
 
 def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=False, dy_out=None, acc_dy=False,
-           dgamma=None, dbeta=None, acc_param=False, training=True):
+           dgamma=None, dbeta=None, acc_param=False, training=True, sums=None):
     C = y.shape[-1]
     rows = y.numel() // C
     gm = g
@@ -178,8 +190,11 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
     elif relu:
         gm = g * ((y * bn[0] + bn[1]) > 0)
     xhat = (y - bn[2]) * bn[3]
-    s0 = gm.reshape(-1, C).double().sum(0).to(y.dtype)
-    s1 = (gm * xhat).reshape(-1, C).double().sum(0).to(y.dtype)
+    if sums is None:
+        s0 = gm.reshape(-1, C).double().sum(0).to(y.dtype)
+        s1 = (gm * xhat).reshape(-1, C).double().sum(0).to(y.dtype)
+    else:
+        s0, s1 = sums[0], sums[1]
     if dgamma is not None:
         if acc_param:
             dgamma.add_(s1); dbeta.add_(s0)

@@ -547,3 +547,44 @@ def test_wide_channel_batchnorm_reductions(ops):
     dy_r, _ = E.bn_bwd(g, y, bn_ref, gamma, relu=True, dgamma=dg_r, dbeta=db_r)
     dy, _ = ops.bn_bwd(g.to(DEV), y.to(DEV), bn_ref.to(DEV), gamma.to(DEV), relu=True, dgamma=dg, dbeta=db)
     close(dy, dy_r, 2e-5, "bn_bwd C=2048"); close(dg, dg_r, 2e-5, "dgamma C=2048")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,masked,acc", [
+    (2, 24, 40, 64, 64, 3, 1, False, False),      # conv2 data gradient -> bn1 (ReLU mask recomputed from y)
+    (3, 17, 29, 128, 128, 3, 1, True, True),      # conv1 data gradient accumulating into the residual gradient -> previous bn2
+    (2, 16, 24, 64, 128, 3, 2, True, True),       # stride 2: four parity-class launches, one set of sums
+    (4, 33, 47, 128, 128, 1, 1, True, True),      # skip projection (1x1) as the last writer
+    (64, 96, 96, 64, 64, 3, 1, False, False),     # > 2048 row tiles: two-level final reduce
+])
+def test_conv_dgrad_with_batchnorm_backward_sums(ops, N, H, W, Cin, Cout, k, s, masked, acc):
+    """dcs_conv_gather_bnbwd: the data gradient's epilogue also reduces sum(gm) and sum(gm * xhat) of the BatchNorm
+    backward that consumes it (gm = final value x ReLU mask).  The gradient itself must be unchanged, the sums must equal
+    what the stand-alone reduction pass (dcs_colsum_partial mode 1) computes from the written tensor."""
+    pad = k // 2
+    OH, OW = E.conv_fwd(torch.zeros(1, H, W, Cin), cl(torch.zeros(Cout, Cin, k, k)), s, pad).shape[1:3]
+    dy = rnd(N, OH, OW, Cout, seed=71)
+    w = cl(rnd(Cout, Cin, k, k, seed=72, scale=0.05))
+    y = rnd(N, H, W, Cin, seed=73) * 1.5 + 0.3
+    mask = torch.relu(rnd(N, H, W, Cin, seed=74)) if masked else None
+    base = rnd(N, H, W, Cin, seed=75)
+    gamma, beta = rnd(Cin, seed=76) * 0.1 + 1, rnd(Cin, seed=77) * 0.1
+    yd, dyd, wd = y.to(DEV), dy.to(DEV), cl(w.to(DEV))
+    bn = ops.bn_finalize(ops.colsum(yd.reshape(-1, Cin), moments=True), gamma.to(DEV), beta.to(DEV), torch.zeros(Cin, device=DEV),
+                         torch.ones(Cin, device=DEV), N * H * W, True)
+    wp = ops.pack_dgrad_weight(wd)
+    md = mask.to(DEV) if masked else None
+    ref_out = base.to(DEV).clone() if acc else None
+    ref = ops.conv_dgrad(dyd, wp, (H, W), s, pad, out=ref_out, accumulate=acc)
+    out = base.to(DEV).clone() if acc else None
+    got, sums = ops.conv_dgrad(dyd, wp, (H, W), s, pad, out=out, accumulate=acc, bnb=(yd, md, bn, not masked))
+    assert sums is not None and torch.equal(got, ref)
+    dg, db = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+    dy_a, _ = ops.bn_bwd(ref, yd, bn, gamma.to(DEV), masksrc=md, relu=not masked, dgamma=dg, dbeta=db)
+    dg2, db2 = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
+    dy_b, _ = ops.bn_bwd(got, yd, bn, gamma.to(DEV), masksrc=md, relu=not masked, dgamma=dg2, dbeta=db2, sums=sums)
+    close(db2, db.cpu(), 2e-5, "sum gm (dbeta)")
+    close(dg2, dg.cpu(), 2e-5, "sum gm * xhat (dgamma)")
+    close(dy_b, dy_a.cpu(), 2e-5, "BatchNorm backward with the fused sums")
+    got2, sums2 = ops.conv_dgrad(dyd, wp, (H, W), s, pad, out=(base.to(DEV).clone() if acc else None), accumulate=acc,
+                                 bnb=(yd, md, bn, not masked))
+    assert torch.equal(sums, sums2)                                   # fixed-order reduction: bitwise reproducible
