@@ -69,14 +69,18 @@ def device_batch(O, b, h, w, seed, two, dev):
 class ConvProfiler:
     """Records a HIP event pair (on the launch stream) around every conv launch of one kind."""
 
+    GEOM_ARG = {"dcs_conv_gather": 4, "dcs_conv_gather_pro": 4, "dcs_conv_gather_split": 3, "dcs_conv_gather_bnbwd": 3,
+                "dcs_conv_wgrad": 3, "dcs_conv_wgrad_pro": 3}      # position of the DcsConvGeom argument
+
     def __init__(self, ops):
         self.ops, self.records, self.enabled = ops, [], False
         self._orig = ops._call
 
         def wrapped(name, *args):
             # every launch of the implicit-GEMM kernels: plain, split-K (its slab reduce is timed with it) and wgrad
-            if self.enabled and name in ("dcs_conv_gather", "dcs_conv_gather_split", "dcs_conv_wgrad"):
-                g = args[3]._obj if name != "dcs_conv_gather" else args[4]._obj
+            # (also the launches with a fused BatchNorm prologue "_pro" or BatchNorm-backward epilogue "_bnbwd")
+            if self.enabled and name in self.GEOM_ARG:
+                g = args[self.GEOM_ARG[name]]._obj
                 M = g.N * g.TY * g.TX
                 flops = 2.0 * M * (147 if g.stem else g.ntaps * g.K) * g.Cout
                 # algorithmic bytes: gathered tensor once + produced tensor once + weights once
@@ -85,8 +89,10 @@ class ConvProfiler:
                 e0.record()
                 self._orig(name, *args)
                 e1.record()
-                kind = "dcs_conv_wgrad" if name == "dcs_conv_wgrad" else "dcs_conv_gather"
-                key = (kind, g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy, g.stem)
+                kind = "dcs_conv_wgrad" if name.startswith("dcs_conv_wgrad") else "dcs_conv_gather"
+                fused = name.rsplit("_", 1)[1] if name.endswith(("_pro", "_bnbwd")) else ""
+                key = (kind + ("+" + fused if fused else ""), g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy,
+                       g.stem)
                 self.records.append((kind, flops, e0, e1, key, abytes))
             else:
                 self._orig(name, *args)

@@ -41,6 +41,16 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 // BatchNorm-backward sums in a data-gradient epilogue (see conv_epilogue): y = the input of the BatchNorm whose
 // output gradient this launch produces (same [M][dst_cstride] layout as dst), mask = the tensor whose sign is the ReLU
 // mask (nullable), bn = [scale, shift, mean, invstd] x C record, relu = derive the mask from y*scale+shift.
+// BatchNorm + ReLU prologue on a staged float4: relu(v * sc + sh), or 0 where the element is padding (lim = 0; +inf on real
+// elements): two packed FMAs and four v_med3_f32 (clamp to [0, lim]) instead of fma + max + select per float.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 pro_apply(const float4 v, const float4 sc, const float4 sh, const float lim) {
+  const f32x2 lo = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});
+  const f32x2 hi = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
+  return make_float4(__builtin_amdgcn_fmed3f(lo.x, 0.f, lim), __builtin_amdgcn_fmed3f(lo.y, 0.f, lim),
+                     __builtin_amdgcn_fmed3f(hi.x, 0.f, lim), __builtin_amdgcn_fmed3f(hi.y, 0.f, lim));
+}
+
 struct BnBwdEpi { const float* y; const float* mask; const float* bn; int relu; };
 
 // Epilogue shared by the convolution kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
@@ -184,7 +194,7 @@ __global__ __launch_bounds__(256, (BKT == 16 && BM * BN <= 128 * 128) ? 3 : 2)
 void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__ wgt,
                         const float* __restrict__ bias, float* __restrict__ dst,
                         const DcsConvGeom g, const int accumulate, const int ntiles, float* __restrict__ stats,
-                        const int cps, const long long slab_stride, const BnBwdEpi bnb) {
+                        const int cps, const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro) {
   constexpr int WN = (BN >= 128 || (BN == 64 && BM == 128)) ? 2 : 1;
   constexpr int WM = 4 / WN;
   constexpr int TM = BM / (WM * 32);
@@ -203,12 +213,20 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   float (*Bs)[BN * LDKT] = reinterpret_cast<float (*)[BN * LDKT]>(smem + 2 * BM * LDKT);
   __shared__ long long rowoff[BM];
   __shared__ int s_oy[DCS_MAX_TAPS], s_ox[DCS_MAX_TAPS], s_wo[DCS_MAX_TAPS], s_to[DCS_MAX_TAPS];
+  // BatchNorm + ReLU prologue (network/utils.py:35-49 _BNReluConv, resnet_pyramid.py:71-89 conv2 of a BasicBlock): the
+  // source tensor is the BatchNorm INPUT; scale / shift / max(.,0) are applied to the A operand on its way from the
+  // staging registers to LDS, so the activated tensor is never written.  pro = [scale(K), shift(K)] (the head of the
+  // BatchNorm record).  Zero padding is padding of the ACTIVATED tensor: out-of-range taps stay exactly 0.
+  __shared__ __attribute__((aligned(16))) float s_pro[STEM ? 4 : 2 * DCS_PRO_MAXK];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
   const int lrow = tid / C4, lcol4 = tid % C4;
+  const bool has_pro = !STEM && pro != nullptr;
+  if (has_pro)
+    for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
 
   const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
   const int ntile = bid % ntiles, mtile = bid / ntiles;
@@ -284,12 +302,19 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     c_kc = c0 + lcol4 * 4;
     c_kvalid = STEM ? true : c_kc < g.K;
   };
+  float lim[NA];                     // prologue only: +inf if the A slot's registers hold a real (in-range) element, else 0
+  float4 p_sc = zero4(), p_sh = zero4();   // prologue scale / shift of the channels of the chunk held in the registers
+  auto load_pro = [&](int kc) {
+    const int kq = kc < g.K ? kc : 0;
+    p_sc = ld4(&s_pro[kq]); p_sh = ld4(&s_pro[DCS_PRO_MAXK + kq]);
+  };
   auto load_slot = [&](int sl) {
     if (sl < NA) {
       const int i = sl;
       if (!STEM) {
         const bool ok = c_kvalid && (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH && (unsigned)(r_x[i] + c_ox) < (unsigned)g.SW;
         rs[sl] = bld4(rsA, ok ? (unsigned)(r_base[i] + c_to + c_kc) * 4u : OOB);
+        if (has_pro) lim[sl] = ok ? __builtin_inff() : 0.f;
       } else {
         const bool ok = lcol4 < 7 && (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH &&
                         (unsigned)(r_x[i] + c_ox + lcol4) < (unsigned)g.SW;
@@ -301,8 +326,11 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     }
   };
   auto store_slot = [&](int sl, int buf) {
-    if (sl < NA) *reinterpret_cast<float4*>(&As[buf][(lrow + RPP * sl) * LDKT + lcol4 * 4]) = rs[sl];
-    else         *reinterpret_cast<float4*>(&Bs[buf][(lrow + RPP * (sl - NA)) * LDKT + lcol4 * 4]) = rs[sl];
+    if (sl < NA) {
+      float4 v = rs[sl];
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[sl]);
+      *reinterpret_cast<float4*>(&As[buf][(lrow + RPP * sl) * LDKT + lcol4 * 4]) = v;
+    } else *reinterpret_cast<float4*>(&Bs[buf][(lrow + RPP * (sl - NA)) * LDKT + lcol4 * 4]) = rs[sl];
   };
 
   f32x16 acc[TM][TN];
@@ -318,9 +346,11 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   // in iteration ch-1, before the barrier) and immediately re-loaded with chunk ch+2, one slot per pair of MFMAs,
   // so LDS writes, address arithmetic and load issue sit in the shadow of the matrix pipe and every global load
   // has a full iteration (>= 48 MFMAs per wave) to land.  The tail iterations re-load the last chunk (harmless).
+  if (has_pro) __syncthreads();                       // s_pro visible before the first activated store
   set_chunk(cbeg < nch ? cbeg : nch - 1);
 #pragma unroll
   for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  if (has_pro) load_pro(c_kc);
 #pragma unroll
   for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, 0);
   set_chunk(cbeg + 1 < cend ? cbeg + 1 : (cbeg < nch ? cbeg : nch - 1));
@@ -358,6 +388,7 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
     frag_load(0, Ab, Bb, 0);
     frag_load(1, Ab, Bb, 8);
     mfma_range(0, 0, G);
+    if (has_pro) load_pro(c_kc);                          // the registers hold chunk ch + 1: its channels' scale / shift
     set_chunk(ch + 2 < cend ? ch + 2 : cend - 1);
     if (NG == 4) frag_load(0, Ab, Bb, 16);
 #pragma unroll
@@ -387,7 +418,7 @@ template <int BT, int CH = 32>
 __global__ __launch_bounds__(256, (BT == 128 && CH == 16) ? 4 : 2)
 void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                        const DcsConvGeom g, const int dy_cstride, const int split0, const long long mps,
-                       const int ciT) {
+                       const int ciT, const float* __restrict__ pro) {
   constexpr int T = BT / 64;          // 32x32 tiles per wave per dim
   constexpr int C4 = BT / 4;          // float4 per staged row
   constexpr int RP = 256 / C4;        // rows per load pass
@@ -430,6 +461,11 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
   float4 rd[NP], rx[NP];
   const int kc = ci0 + lcol4 * 4;
   const int cc = co0 + lcol4 * 4;
+  // BatchNorm + ReLU prologue on the source operand (see conv_gather_kernel): a thread's channels never change
+  const bool has_pro = pro != nullptr && !g.stem;
+  float4 p_sc = zero4(), p_sh = zero4();
+  if (has_pro && kc < g.K) { p_sc = ld4(pro + kc); p_sh = ld4(pro + g.K + kc); }
+  float lim[NP];                     // +inf where rx[i] holds a real element, 0 where it is padding (prologue only)
   // 32-bit buffer addressing relative to this split's first dy row / first source image
   const int n0 = (int)(mbeg / TYX);
   const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
@@ -456,6 +492,7 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
         off = (((p_n[i] - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride;
       }
       rx[i] = bld4(rsX, ok ? (unsigned)off * 4u : OOB);
+      if (has_pro) lim[i] = ok ? __builtin_inff() : 0.f;
       // advance this slot by one chunk of pixels
       p_tx[i] += CH;
       while (p_tx[i] >= g.TX) { p_tx[i] -= g.TX; p_ty[i] += 1; }
@@ -466,7 +503,9 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
       *reinterpret_cast<float4*>(&Ds[buf][(lrow + RP * i) * BT + lcol4 * 4]) = rd[i];
-      *reinterpret_cast<float4*>(&Xs[buf][(lrow + RP * i) * BT + lcol4 * 4]) = rx[i];
+      float4 v = rx[i];
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[i]);
+      *reinterpret_cast<float4*>(&Xs[buf][(lrow + RP * i) * BT + lcol4 * 4]) = v;
     }
   };
 
@@ -536,7 +575,7 @@ void conv_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad3x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                           const DcsConvGeom g, const int dy_cstride, const int split0, const int cps /*chunks per split*/,
-                          const int ciT) {
+                          const int ciT, const float* __restrict__ pro) {
   constexpr int HW_ = 34;                 // halo width in pixels
   constexpr int XROWS = 3 * HW_;          // 102 staged input rows
   constexpr int NSD = 2, NSX = 7, NSLOT = NSD + NSX;
@@ -575,6 +614,11 @@ void conv_wgrad3x3_kernel(const float* __restrict__ src, const float* __restrict
   const __amdgpu_buffer_rsrc_t rsD = make_rsrc(dy + mbeg * dy_cstride, (long long)nch * 32 * dy_cstride * 4);
   const int kc = ci0 + lcol4 * 4, cc = co0 + lcol4 * 4;
   const bool kok = kc < g.K, ccok = cc < g.Cout;
+  // BatchNorm + ReLU prologue on the source operand (see conv_gather_kernel): a thread's channels never change
+  const bool has_pro = pro != nullptr;
+  float4 p_sc = zero4(), p_sh = zero4();
+  if (has_pro && kok) { p_sc = ld4(pro + kc); p_sh = ld4(pro + g.K + kc); }
+  float lim[NSX];                    // +inf where the halo slot holds a real element, 0 where it is padding (prologue only)
 
   // per-slot constants of the halo rows this thread stages
   int xs_hr[NSX], xs_hx[NSX];
@@ -600,6 +644,7 @@ void conv_wgrad3x3_kernel(const float* __restrict__ src, const float* __restrict
       const bool ok = xs_ok[k] && kok && l_chunk < nch && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
       const int off = (((q_n - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
       rs[sl] = bld4(rsX, ok ? (unsigned)off * 4u : OOB);
+      if (has_pro) lim[k] = ok ? __builtin_inff() : 0.f;
     }
   };
   auto advance_chunk = [&]() {
@@ -613,7 +658,9 @@ void conv_wgrad3x3_kernel(const float* __restrict__ src, const float* __restrict
       *reinterpret_cast<float4*>(&Ds[buf][(lrow + 16 * sl) * 64 + lcol4 * 4]) = rs[sl];
     } else {
       const int k = sl - NSD;
-      if (xs_ok[k]) *reinterpret_cast<float4*>(&Xs[buf][(tid + 256 * k) * 4]) = rs[sl];
+      float4 v = rs[sl];
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[k]);
+      if (xs_ok[k]) *reinterpret_cast<float4*>(&Xs[buf][(tid + 256 * k) * 4]) = v;
     }
   };
 
@@ -941,7 +988,7 @@ static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
 
 static int launch_gather(const float* src, const float* wgt, const float* bias, float* dst, const DcsConvGeom* geom,
                          int accumulate, float* stats, int nsplit, long long slab_stride, void* stream,
-                         const BnBwdEpi bnb = BnBwdEpi{nullptr, nullptr, nullptr, 0}) {
+                         const BnBwdEpi bnb = BnBwdEpi{nullptr, nullptr, nullptr, 0}, const float* pro = nullptr) {
   int rc = check_geom(geom);
   if (rc != DCS_OK) return rc;
   DCS_CHECK_ARG(src && wgt && dst && dcs_aligned16(src) && dcs_aligned16(wgt));
@@ -963,6 +1010,7 @@ static int launch_gather(const float* src, const float* wgt, const float* bias, 
   const int bn = geom->Cout > 64 ? 128 : (geom->Cout > 32 ? 64 : 32);
   const int ntiles = (geom->Cout + bn - 1) / bn;
   DCS_CHECK_ARG(!(stats && accumulate && !bnb.y));
+  DCS_CHECK_ARG(!pro || (!geom->stem && geom->K <= DCS_PRO_MAXK && dcs_aligned16(pro)));
   // BatchNorm-backward sums: dense vectorised destination, y (and mask) share its layout
   DCS_CHECK_ARG(!bnb.y || (stats && bnb.bn && nsplit == 1 && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
                            dcs_aligned16(dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
@@ -980,7 +1028,7 @@ static int launch_gather(const float* src, const float* wgt, const float* bias, 
   hipStream_t s = dcs_stream(stream);
 #define LAUNCH_K(...)                                                                                                  \
   hipLaunchKernelGGL((conv_gather_kernel<__VA_ARGS__>), dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, \
-                     wgt, bias, dst, *geom, accumulate, ntiles, stats, cps, slab_stride, bnb)
+                     wgt, bias, dst, *geom, accumulate, ntiles, stats, cps, slab_stride, bnb, pro)
   if (geom->stem) {
     // 14-tap stem geometry = half filter rows of 4 pixels (16 floats): 16-float chunks, 32.5 KB LDS, more blocks per CU
     if (stem14) LAUNCH_K(64, true, 16);
@@ -1004,6 +1052,19 @@ extern "C" int dcs_conv_gather(const float* src, const float* wgt, const float* 
   return launch_gather(src, wgt, bias, dst, geom, accumulate, stats, 1, 0, stream);
 }
 
+extern "C" int dcs_conv_gather_pro(const float* src, const float* wgt, const float* bias, float* dst, const DcsConvGeom* geom,
+                                   int accumulate, float* stats, const float* pro, int nsplit, int64_t slab_stride,
+                                   void* stream) {
+  DCS_CHECK_ARG(pro && nsplit >= 1);
+  if (nsplit > 1) {
+    DCS_CHECK_ARG(geom && !bias && !stats && !accumulate &&
+                  slab_stride >= (int64_t)geom->N * geom->DH * geom->DW * geom->dst_cstride);
+    return launch_gather(src, wgt, nullptr, dst, geom, 0, nullptr, nsplit, slab_stride, stream,
+                         BnBwdEpi{nullptr, nullptr, nullptr, 0}, pro);
+  }
+  return launch_gather(src, wgt, bias, dst, geom, accumulate, stats, 1, 0, stream, BnBwdEpi{nullptr, nullptr, nullptr, 0}, pro);
+}
+
 extern "C" int dcs_conv_gather_bnbwd(const float* src, const float* wgt, float* dst, const DcsConvGeom* geom, int accumulate,
                                      const float* bn_y, const float* bn_mask, const float* bn, int relu, float* part,
                                      void* stream) {
@@ -1021,8 +1082,22 @@ extern "C" int dcs_conv_gather_split(const float* src, const float* wgt, float* 
 // chunks at 2 blocks per CU on the 1x1 layers (the kernel is stall-bound, not MFMA-bound).  DCS_WGRAD_CH32 restores 32.
 static const bool g_wgrad_ch16 = getenv("DCS_WGRAD_CH32") == nullptr;
 
+static int launch_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride, int split0,
+                        int nsplit, void* stream, const float* pro);
+
 extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom,
                               int dy_cstride, int split0, int nsplit, void* stream) {
+  return launch_wgrad(src, dy, slab, geom, dy_cstride, split0, nsplit, stream, nullptr);
+}
+
+extern "C" int dcs_conv_wgrad_pro(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
+                                  int split0, int nsplit, const float* pro, void* stream) {
+  DCS_CHECK_ARG(pro && geom && !geom->stem && dcs_aligned16(pro));
+  return launch_wgrad(src, dy, slab, geom, dy_cstride, split0, nsplit, stream, pro);
+}
+
+static int launch_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride, int split0,
+                        int nsplit, void* stream, const float* pro) {
   int rc = check_geom(geom);
   if (rc != DCS_OK) return rc;
   DCS_CHECK_ARG(src && dy && slab && dcs_aligned16(src) && dcs_aligned16(dy));
@@ -1054,7 +1129,7 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
     const long long span = ((long long)cps * 32 + 4ll * geom->SW) * geom->src_cstride * 4;
     if ((long long)cps * 32 * dy_cstride * 4 < 0x7FFFFFFFll && span < 0x7FFFFFFFll) {
       hipLaunchKernelGGL(conv_wgrad3x3_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0,
-                         dcs_stream(stream), src, dy, slab, *geom, dy_cstride, split0, cps, ciT);
+                         dcs_stream(stream), src, dy, slab, *geom, dy_cstride, split0, cps, ciT, pro);
       DCS_LAUNCH_RET();
     }
   }
@@ -1065,11 +1140,11 @@ extern "C" int dcs_conv_wgrad(const float* src, const float* dy, float* slab, co
   dim3 grid((unsigned)(geom->ntaps * coT * ciT), (unsigned)nsplit);
   if (bt == 128)
     if (g_wgrad_ch16)
-      hipLaunchKernelGGL((conv_wgrad_kernel<128, 16>), grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
+      hipLaunchKernelGGL((conv_wgrad_kernel<128, 16>), grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT, pro);
     else
-      hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
+      hipLaunchKernelGGL(conv_wgrad_kernel<128>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT, pro);
   else
-    hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT);
+    hipLaunchKernelGGL(conv_wgrad_kernel<64>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT, pro);
   DCS_LAUNCH_RET();
 }
 

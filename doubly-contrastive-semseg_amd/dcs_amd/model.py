@@ -272,8 +272,8 @@ class SwiftNetEngine:
             OH, OW = sk[0].shape[1:3]
             t = ops.upsample_add(x, sk, OH, OW)
             bn = self._bn(t, blend.norm, training)
-            z = ops.bn_act(t, bn, relu=True)
-            xn = ops.conv_fwd(z, blend.conv.weight, 1, 1)
+            z, pro = self._activated(t, bn)
+            xn = ops.conv_fwd(z, blend.conv.weight, 1, 1, pro=pro)
             if need_grad:
                 tape.append(("blend", i, x.shape[1:3], t, bn, z, blend))
             x = xn
@@ -284,8 +284,8 @@ class SwiftNetEngine:
             h, w = fine_feat.shape[1:3]
             ff0 = fine_feat[:B]
             bnh = self._bn(ff0, self.seg.norm, training, rows=B * h * w)
-            zh = ops.bn_act(ff0, bnh, relu=True)
-            before = ops.conv_fwd(zh, self.seg.conv.weight, 1, 0, bias=self.seg.conv.bias, dst_cs=LOGIT_CS)
+            zh, pro = self._activated(ff0, bnh)
+            before = ops.conv_fwd(zh, self.seg.conv.weight, 1, 0, bias=self.seg.conv.bias, dst_cs=LOGIT_CS, pro=pro)
             seg = None if lazy_seg else ops.upsample_to_nchw(before, self.num_classes, H, W)
             if need_grad:
                 tape.append(("head", ff0, bnh, zh, (H, W)))
@@ -296,16 +296,27 @@ class SwiftNetEngine:
             saved.tape, saved.training, saved.B, saved.Bm = tape, training, B, Bm
         return seg, before, fine_feat, saved
 
+    @staticmethod
+    def _activated(y, bn):
+        """relu(BatchNorm(y)) as the source operand of the next convolution: (y, bn) when the convolution kernels apply
+        it as their prologue (the activated tensor is then never materialised -- the backward's weight gradient takes
+        the same pair), else (the materialised tensor, None)."""
+        if y.is_contiguous() and ops.pro_ok(y.shape[-1]):
+            return y, bn
+        return ops.bn_act(y, bn, relu=True), None
+
     def _block_fwd(self, x, blk: BasicBlock, training, tape):
         s = blk.stride
 
-        def conv(inp, w, stride, pad):        # conv + (in training) the BN batch statistics from its epilogue
-            return ops.conv_fwd(inp, w, stride, pad, want_stats=True) if training else (ops.conv_fwd(inp, w, stride, pad), None)
+        def conv(inp, w, stride, pad, pro=None):   # conv + (in training) the BN batch statistics from its epilogue
+            if training:
+                return ops.conv_fwd(inp, w, stride, pad, want_stats=True, pro=pro)
+            return ops.conv_fwd(inp, w, stride, pad, pro=pro), None
 
         y1, st1 = conv(x, blk.conv1.weight, s, 1)
         bn1 = self._bn(y1, blk.bn1, training, sums=st1)
-        z1 = ops.bn_act(y1, bn1, relu=True)
-        y2, st2 = conv(z1, blk.conv2.weight, 1, 1)
+        z1, pro1 = self._activated(y1, bn1)
+        y2, st2 = conv(z1, blk.conv2.weight, 1, 1, pro1)
         bn2 = self._bn(y2, blk.bn2, training, sums=st2)
         yd = bnd = None
         if blk.downsample is not None:
@@ -326,12 +337,16 @@ class SwiftNetEngine:
         packed: Dict[nn.Parameter, torch.Tensor] = {}
         training = saved.training
 
-        def wgrad(conv, x, dy, stride, pad):
+        def wgrad(conv, x, dy, stride, pad, pro=None):
             w = conv.weight
             acc = w in grads
             if not acc:
                 grads[w] = self._galloc(w)
-            ops.conv_wgrad(x, dy, grads[w], stride, pad, acc)
+            ops.conv_wgrad(x, dy, grads[w], stride, pad, acc, pro=pro)
+
+        def pro_of(z, y, bn):
+            """The forward kept y itself where the consumer applied BatchNorm + ReLU as its prologue (_activated)."""
+            return bn if z is y else None
 
         def wp(conv):
             w = conv.weight
@@ -366,7 +381,7 @@ class SwiftNetEngine:
                     ops.axpy(gb, g_before.contiguous(), 1.0)
             if gb is not None:
                 seg = self.seg
-                wgrad(seg.conv, zh, gb, 1, 0)
+                wgrad(seg.conv, zh, gb, 1, 0, pro_of(zh, ff0, bnh))
                 bsum = ops.colsum(gb.reshape(-1, LOGIT_CS))
                 grads[seg.conv.bias] = self._galloc(seg.conv.bias)
                 grads[seg.conv.bias].copy_(bsum[0, 0, :self.num_classes])
@@ -391,7 +406,7 @@ class SwiftNetEngine:
         while pos >= 0 and tape[pos][0] == "blend":
             _, i, in_hw, t, bn, z, blend = tape[pos]
             pos -= 1
-            wgrad(blend.conv, z, g_x, 1, 1)
+            wgrad(blend.conv, z, g_x, 1, 1, pro_of(z, t, bn))
             g_z, bs = ops.conv_dgrad(g_x, wp(blend.conv), t.shape[1:3], 1, 1, bnb=(t, None, bn, True))
             g_t, _ = bn_bwd(blend.norm, g_z, t, bn, relu=True, sums=bs)
             g_skip[5 - i] = g_t                      # skips[idx + li] with idx + li = 5 - i
@@ -434,7 +449,7 @@ class SwiftNetEngine:
                     ops.bn_ema_again(bn2, blk.bn2.running_mean, blk.bn2.running_var, y2.numel() // y2.shape[-1],
                                      momentum=blk.bn2.momentum)
                     self._nbt.append(blk.bn2)
-                wgrad(blk.conv2, z1, dy2, 1, 1)
+                wgrad(blk.conv2, z1, dy2, 1, 1, pro_of(z1, y1, bn1))
                 g_z1, s1 = ops.conv_dgrad(dy2, wp(blk.conv2), z1.shape[1:3], 1, 1, bnb=(y1, None, bn1, True))
                 dy1, _ = bn_bwd(blk.bn1, g_z1, y1, bn1, relu=True, sums=s1)
                 if training:

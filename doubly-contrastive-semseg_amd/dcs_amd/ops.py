@@ -150,6 +150,7 @@ def geom_stem(N, H, W):
 # convolution
 # --------------------------------------------------------------------------- #
 CONV_BM = 128
+PRO_MAXK = 512            # DCS_PRO_MAXK of include/dcs_hip.h
 
 
 def _stats_buffer(M, Cout, dev):
@@ -191,19 +192,36 @@ def _ksplit(g, M, Cout):
     return int(max(1, min(16, 512 // blocks, nch32 // 6)))
 
 
-def _gather_split(src, wgt, g, ns, dst, accumulate):
+def _gather_split(src, wgt, g, ns, dst, accumulate, pro=None):
     """Split-K launch + fixed-order slab reduce into dst (dense [N,DH,DW,Cout])."""
     n = dst.numel()
     slab = torch.empty((ns, n), device=dst.device, dtype=_F32)
-    _call("dcs_conv_gather_split", _p(src), _p(wgt), _p(slab), C.byref(g), ns, n, _stream())
+    if pro is None:
+        _call("dcs_conv_gather_split", _p(src), _p(wgt), _p(slab), C.byref(g), ns, n, _stream())
+    else:
+        _call("dcs_conv_gather_pro", _p(src), _p(wgt), None, _p(slab), C.byref(g), 0, None, _p(pro), ns, n, _stream())
     _call("dcs_reduce_slab", _p(slab), _p(dst), n, ns, 1 if accumulate else 0, 0, 0, _stream())
 
 
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None):
+def _gather(src, wgt, bias, dst, g, accumulate, stats, pro):
+    if pro is None:
+        _call("dcs_conv_gather", _p(src), _p(wgt), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats), _stream())
+    else:
+        _call("dcs_conv_gather_pro", _p(src), _p(wgt), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats), _p(pro), 1, 0,
+              _stream())
+
+
+def pro_ok(Cin):
+    """Can a convolution over Cin source channels apply the BatchNorm + ReLU of its input as a prologue?"""
+    return Cin <= PRO_MAXK and os.environ.get("DCS_PROLOGUE", "1") != "0"
+
+
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None, pro=None):
     """nn.Conv2d forward.  x [N,H,W,Cin]; w OIHW channels_last; -> [N,OH,OW,dst_cs or Cout].
     want_stats: also return sums [1,2,Cout] (per-channel sum / sum of squares of the output) from the fused epilogue.
     koff: x holds the input-channel slice [koff, koff+Cin) of a wider weight (the other slices belong to other
-    tensors of a concatenation); out: accumulate into this tensor instead of allocating (sum over the slices)."""
+    tensors of a concatenation); out: accumulate into this tensor instead of allocating (sum over the slices).
+    pro: BatchNorm record [4,Cin] of x -- the convolution reads relu(x * scale + shift) (pro_ok(Cin) must hold)."""
     _req(x)
     N, H, W, Cin = x.shape
     Cout, Ktot, R, S = w.shape
@@ -213,20 +231,20 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1,
     if out is not None:
         assert not want_stats
         if ns > 1 and out.is_contiguous():
-            _gather_split(x, krsc(w), g, ns, out, True)
+            _gather_split(x, krsc(w), g, ns, out, True, pro)
         else:
-            _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(out), C.byref(g), 1, None, _stream())
+            _gather(x, krsc(w), bias, out, g, 1, None, pro)
         return out
     alloc = torch.zeros if cs != Cout else torch.empty
     y = alloc((N, g.DH, g.DW, cs), device=x.device, dtype=_F32)
     if ns > 1:
-        _gather_split(x, krsc(w), g, ns, y, False)
+        _gather_split(x, krsc(w), g, ns, y, False, pro)
         return (y, colsum(y.reshape(-1, Cout), moments=True)) if want_stats else y
     if not want_stats:
-        _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, None, _stream())
+        _gather(x, krsc(w), bias, y, g, 0, None, pro)
         return y
     part, G, G1 = _stats_buffer(N * g.DH * g.DW, Cout, x.device)
-    _call("dcs_conv_gather", _p(x), _p(krsc(w)), _p(bias), _p(y), C.byref(g), 0, _p(part), _stream())
+    _gather(x, krsc(w), bias, y, g, 0, part, pro)
     return y, _stats_reduce(part, G, G1, Cout, N * g.DH * g.DW)
 
 
@@ -314,9 +332,9 @@ def _nsplit(tiles, M, blocks=1024):
     return max(1, min(-(-blocks // tiles), -(-M // 256)))
 
 
-def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
+def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
     """Weight gradient into dw (OIHW channels_last, same layout as the parameter).  koff: x is the input-channel
-    slice [koff, koff+Cin) of the convolution, only that slice of dw is written."""
+    slice [koff, koff+Cin) of the convolution, only that slice of dw is written.  pro: as in conv_fwd."""
     _req(x), _req(dy)
     N, H, W, Cin = x.shape
     Cout, Ktot, R, S = dw.shape
@@ -333,7 +351,10 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
         ns = _nsplit(tiles, M, 2048 if bt == 64 else 1024)
     n = Cout * R * S * Cin
     slab = torch.empty((ns, n), device=x.device, dtype=_F32)
-    _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())
+    if pro is None:
+        _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())
+    else:
+        _call("dcs_conv_wgrad_pro", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _p(pro), _stream())
     if koff is None and Ktot == Cin:
         _call("dcs_reduce_slab", _p(slab), _p(krsc(dw)), n, ns, 1 if accumulate else 0, 0, 0, _stream())
     else:

@@ -89,6 +89,18 @@ int dcs_conv_gather_split(const float* src, const float* wgt, float* slab, const
 int dcs_conv_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom,
                    int dy_cstride, int split0, int nsplit, void* stream);
 
+/* Convolution / weight gradient of the ACTIVATED source: the operand is relu(src * scale[k] + shift[k]) (zero in the
+ * padding, exactly as a convolution of the materialised activation), applied on the way from the staging registers into
+ * LDS, so the BatchNorm + ReLU output between two convolutions (network/backbone/resnet_pyramid.py:62-66 conv2 of a
+ * BasicBlock; network/utils.py:44-47 _BNReluConv) is never written to or read from HBM.  pro = [scale(K), shift(K)], the
+ * head of a dcs_bn_finalize record; K <= DCS_PRO_MAXK, not for the stem.  dcs_conv_gather_pro: nsplit > 1 is the
+ * split-K form (dst = slab, see dcs_conv_gather_split; no bias / stats / accumulate). */
+#define DCS_PRO_MAXK 512
+int dcs_conv_gather_pro(const float* src, const float* wgt, const float* bias, float* dst, const DcsConvGeom* geom,
+                        int accumulate, float* stats, const float* pro, int nsplit, int64_t slab_stride, void* stream);
+int dcs_conv_wgrad_pro(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
+                       int split0, int nsplit, const float* pro, void* stream);
+
 /* dw[o(i)] = (accumulate ? dw[o(i)] : 0) + sum_s slab[s][i], fixed order (deterministic).
  * row_len == 0: o(i) = i.  row_len > 0: the slab holds compact rows of row_len floats that land at stride
  * dst_stride in dw (gradient of a channel slice of a wider weight, "virtual concat" convolutions). */

@@ -31,7 +31,16 @@ def krsc(w):
     return w.permute(0, 2, 3, 1)
 
 
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None):
+PRO_MAXK = 512
+
+
+def pro_ok(Cin):
+    return Cin <= PRO_MAXK
+
+
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None, pro=None):
+    if pro is not None:                                 # contract of dcs_conv_gather_pro
+        x = F.relu(x * pro[0] + pro[1])
     wk = w if koff is None else w[:, koff:koff + x.shape[-1]]
     y = _nhwc(F.conv2d(_nchw(x), wk, bias, stride, pad, dil))
     if out is not None:
@@ -76,7 +85,9 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
     return out, torch.stack([s0, s1])
 
 
-def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None):
+def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
+    if pro is not None:
+        x = F.relu(x * pro[0] + pro[1])
     Cout = dw.shape[0]
     Cin = x.shape[-1]
     shape = (Cout, Cin) + tuple(dw.shape[2:])

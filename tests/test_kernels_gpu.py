@@ -551,7 +551,7 @@ def test_wide_channel_batchnorm_reductions(ops):
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,masked,acc", [
     (2, 24, 40, 64, 64, 3, 1, False, False),      # conv2 data gradient -> bn1 (ReLU mask recomputed from y)
-    (3, 17, 29, 128, 128, 3, 1, True, True),      # conv1 data gradient accumulating into the residual gradient -> previous bn2
+    (4, 73, 71, 128, 128, 3, 1, True, True),      # conv1 data gradient accumulating into the residual gradient -> previous bn2
     (2, 16, 24, 64, 128, 3, 2, True, True),       # stride 2: four parity-class launches, one set of sums
     (4, 33, 47, 128, 128, 1, 1, True, True),      # skip projection (1x1) as the last writer
     (64, 96, 96, 64, 64, 3, 1, False, False),     # > 2048 row tiles: two-level final reduce
@@ -577,7 +577,7 @@ def test_conv_dgrad_with_batchnorm_backward_sums(ops, N, H, W, Cin, Cout, k, s, 
     ref = ops.conv_dgrad(dyd, wp, (H, W), s, pad, out=ref_out, accumulate=acc)
     out = base.to(DEV).clone() if acc else None
     got, sums = ops.conv_dgrad(dyd, wp, (H, W), s, pad, out=out, accumulate=acc, bnb=(yd, md, bn, not masked))
-    assert sums is not None and torch.equal(got, ref)
+    assert sums is not None and torch.equal(got, ref)             # (tiny maps run split-K and return sums = None: not these)
     dg, db = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
     dy_a, _ = ops.bn_bwd(ref, yd, bn, gamma.to(DEV), masksrc=md, relu=not masked, dgamma=dg, dbeta=db)
     dg2, db2 = torch.empty(Cin, device=DEV), torch.empty(Cin, device=DEV)
@@ -588,3 +588,54 @@ def test_conv_dgrad_with_batchnorm_backward_sums(ops, N, H, W, Cin, Cout, k, s, 
     got2, sums2 = ops.conv_dgrad(dyd, wp, (H, W), s, pad, out=(base.to(DEV).clone() if acc else None), accumulate=acc,
                                  bnb=(yd, md, bn, not masked))
     assert torch.equal(sums, sums2)                                   # fixed-order reduction: bitwise reproducible
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,bias,cs", [
+    (2, 24, 64, 64, 64, 3, False, None),        # conv2 of a BasicBlock; nine-tap weight gradient (W % 32 == 0)
+    (2, 37, 29, 128, 128, 3, False, None),      # ragged map: generic weight-gradient kernel, partial row tiles
+    (8, 4, 8, 512, 512, 3, False, None),        # deep layer of a small input: split-K forward, K = DCS_PRO_MAXK
+    (2, 20, 36, 128, 19, 1, True, 20),          # segmentation head: 1x1, bias, padded logits stride
+    (1, 16, 32, 256, 128, 3, False, None),      # wide source, 128-wide tiles
+    (2, 9, 11, 48, 64, 3, False, None),         # source width not a multiple of the 32-channel chunk
+])
+def test_conv_with_batchnorm_relu_prologue(ops, N, H, W, Cin, Cout, k, bias, cs):
+    """dcs_conv_gather_pro / dcs_conv_wgrad_pro: the convolution (and its weight gradient) of relu(y * scale + shift)
+    taken on the fly must be BITWISE the convolution of the materialised activation (same kernel, same operand values,
+    zero in the padding), and equal to the CPU emulation within the fp32 convolution tolerance."""
+    pad = k // 2
+    y = rnd(N, H, W, Cin, seed=91) * 1.3 + 0.2
+    w = cl(rnd(Cout, Cin, k, k, seed=92, scale=0.05))
+    b = rnd(Cout, seed=93) if bias else None
+    gamma, beta = rnd(Cin, seed=94) * 0.1 + 1, rnd(Cin, seed=95) * 0.1 + 0.05
+    yd, wd = y.to(DEV), cl(w.to(DEV))
+    bd = b.to(DEV) if bias else None
+    bn = ops.bn_finalize(ops.colsum(yd.reshape(-1, Cin), moments=True), gamma.to(DEV), beta.to(DEV), torch.zeros(Cin, device=DEV),
+                         torch.ones(Cin, device=DEV), N * H * W, True)
+    assert ops.pro_ok(Cin)
+    z = ops.bn_act(yd, bn, relu=True)
+    stats = not bias
+    ref = ops.conv_fwd(z, wd, 1, pad, bias=bd, dst_cs=cs, want_stats=stats)
+    got = ops.conv_fwd(yd, wd, 1, pad, bias=bd, dst_cs=cs, want_stats=stats, pro=bn)
+    if stats:
+        assert torch.equal(got[1], ref[1])
+        got, ref = got[0], ref[0]
+    assert torch.equal(got, ref)
+    emu = E.conv_fwd(y, w, 1, pad, bias=b, dst_cs=cs, pro=bn.cpu())
+    close(got, emu, 2e-4, "prologue convolution vs emulation")
+    # accumulate form (virtual-concatenation slices)
+    acc0 = rnd(*ref.shape, seed=96).to(DEV)
+    if not bias:
+        a_ref = ops.conv_fwd(z, wd, 1, pad, out=acc0.clone())
+        a_got = ops.conv_fwd(yd, wd, 1, pad, out=acc0.clone(), pro=bn)
+        assert torch.equal(a_got, a_ref)
+    # weight gradient
+    dy = rnd(*ref.shape, seed=97).to(DEV)
+    if cs:
+        dy[..., Cout:] = 0
+    dw_ref, dw_got = cl(torch.empty(Cout, Cin, k, k, device=DEV)), cl(torch.empty(Cout, Cin, k, k, device=DEV))
+    ops.conv_wgrad(z, dy, dw_ref, 1, pad, False)
+    ops.conv_wgrad(yd, dy, dw_got, 1, pad, False, pro=bn)
+    assert torch.equal(dw_got, dw_ref)
+    dw_emu = cl(torch.empty(Cout, Cin, k, k))
+    E.conv_wgrad(y, dy.cpu(), dw_emu, 1, pad, False, pro=bn.cpu())
+    close(dw_got, dw_emu, 2e-4, "prologue weight gradient vs emulation")
