@@ -1,0 +1,343 @@
+// fp32 convolution on the bf16 matrix cores of gfx950: every fp32 operand is split EXACTLY into three bf16 pieces
+// (x = x1 + x2 + x3: 3 x 8 significand bits = the 24 of an fp32) and a product a*b is accumulated in fp32 from the six
+// piece products whose magnitude is >= 2^-16 |a b| (a1b1, a1b2, a2b1, a1b3, a3b1, a2b2); the three dropped ones are
+// <= 2^-24 |a b| each, i.e. below the rounding error of one fp32 multiply-add.  Every piece product is exact in fp32
+// (8 x 8 bits) and v_mfma_f32_32x32x16_bf16 accumulates in fp32, so the result carries fp32-class error (measured
+// against float64 next to the exact-fp32 v_mfma_f32_32x32x2_f32 kernel in tests/test_kernels_gpu.py) at 6/16 of the
+// matrix-pipe time: v_mfma_f32_32x32x2_f32 spends 32 cycles per k, six v_mfma_f32_32x32x16_bf16 spend 12.
+//
+// Same implicit-GEMM gather as conv_igemm.hip (nn.Conv2d forward and its data gradient, network/backbone/
+// resnet_pyramid.py:23-25,:110-112,:139, network/utils.py:46-47), same epilogue (conv_shared.h), same prologue.
+// Tile: 128 output pixels x BN output channels per block of 4 waves; K in chunks of 16 input channels of one tap.
+// LDS row = [piece 1: 16 bf16][piece 2][piece 3][16 B pad] = 112 B (7 x 16 B: odd, ds_read_b128 conflict-free);
+// activations are split on their way from the staging registers to LDS (after the optional BatchNorm + ReLU
+// prologue), weights are split once per launch sequence by dcs_split_weight into exactly this row image
+// [Cout][K chunk][piece][16], so their staging is a straight 96-byte copy.
+#include "conv_shared.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+// (x0, x1) -> the three bf16 pieces of each, packed pairwise (low half = x0's piece).  Round-to-nearest pieces: the
+// remainders are exact in fp32 (Sterbenz), the third remainder has <= 8 significant bits and converts exactly.
+__device__ __forceinline__ void split3_pair(const float x0, const float x1, unsigned& q1, unsigned& q2, unsigned& q3) {
+  const f32x2 v = {x0, x1};
+  const bf16x2 p1 = __builtin_convertvector(v, bf16x2);
+  const f32x2 r1 = v - __builtin_convertvector(p1, f32x2);
+  const bf16x2 p2 = __builtin_convertvector(r1, bf16x2);
+  const f32x2 r2 = r1 - __builtin_convertvector(p2, f32x2);
+  const bf16x2 p3 = __builtin_convertvector(r2, bf16x2);
+  q1 = __builtin_bit_cast(unsigned, p1);
+  q2 = __builtin_bit_cast(unsigned, p2);
+  q3 = __builtin_bit_cast(unsigned, p3);
+}
+
+__device__ __forceinline__ void split3_quad(const float4 v, uint2& p1, uint2& p2, uint2& p3) {
+  split3_pair(v.x, v.y, p1.x, p2.x, p3.x);
+  split3_pair(v.z, v.w, p1.y, p2.y, p3.y);
+}
+
+// w [rows][wstride] fp32 -> out [rows][wstride / 16][3][16] bf16 (the LDS row image of one 16-channel chunk)
+__global__ void split_weight_kernel(const float* __restrict__ w, uint2* __restrict__ out, const long long n4,
+                                    const int wstride) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index
+  if (i >= n4) return;
+  const int s4 = wstride >> 2;
+  const long long row = i / s4;
+  const int k4 = (int)(i - row * s4);
+  const int c = k4 >> 2, q = k4 & 3;
+  uint2 p1, p2, p3;
+  split3_quad(ld4(w + i * 4), p1, p2, p3);
+  uint2* o = out + ((row * (wstride >> 4) + c) * 3) * 4 + q;
+  o[0] = p1; o[4] = p2; o[8] = p3;
+}
+
+constexpr int X3_ROWB = 112;      // bytes per LDS row
+
+template <int BN>
+__global__ __launch_bounds__(256, 2)
+void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
+                           const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom g,
+                           const int accumulate, const int ntiles, float* __restrict__ stats, const int cps,
+                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro) {
+  constexpr int BM = 128, WN = 2, WM = 2, TM = 2, TN = BN / 64;
+  constexpr int A_BYTES = BM * X3_ROWB, B_BYTES = BN * X3_ROWB;
+  constexpr int SMEM_FLOATS = 2 * (A_BYTES + B_BYTES) / 4;
+  constexpr int NA = 2;                      // A slots per thread: 64 rows x 4 float4 each
+  constexpr int NB = (BN * 6 + 255) / 256;   // B slots per thread: 16-byte pieces of the 96-byte row images
+  constexpr int NSLOT = NA + NB;
+  static_assert(BN == 128 || BN == 64, "unsupported tile");
+
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+  __shared__ long long rowoff[BM];
+  __shared__ int s_oy[DCS_MAX_TAPS], s_ox[DCS_MAX_TAPS], s_wo[DCS_MAX_TAPS], s_to[DCS_MAX_TAPS];
+  __shared__ __attribute__((aligned(16))) float s_pro[2 * DCS_PRO_MAXK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int lrow = tid >> 2, lcol4 = tid & 3;
+  const bool has_pro = pro != nullptr;
+  if (has_pro)
+    for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
+
+  const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % ntiles, mtile = bid / ntiles;
+  const int co0 = ntile * BN;
+  const unsigned m0 = (unsigned)mtile * BM;
+  const unsigned TYX = (unsigned)g.TY * (unsigned)g.TX;
+  const unsigned M = (unsigned)g.N * TYX;
+
+  if (tid < BM) {
+    const unsigned m = m0 + tid;
+    long long off = -1;
+    if (m < M) {
+      const int n = (int)(m / TYX);
+      const int rem = (int)(m - (unsigned)n * TYX);
+      const int ty = rem / g.TX, tx = rem - ty * g.TX;
+      off = (((long long)n * g.DH + (ty * g.dsy + g.dy0)) * g.DW + (tx * g.dsx + g.dx0)) * g.dst_cstride;
+    }
+    rowoff[tid] = off;
+  }
+
+  const int n0 = (int)(m0 / TYX);
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const int wchunks = g.wstride >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wsp), (long long)g.Cout * wchunks * 96);
+
+  if (tid < g.ntaps) {
+    s_oy[tid] = g.offy[tid]; s_ox[tid] = g.offx[tid];
+    s_wo[tid] = (g.wofs[tid] >> 4) * 96;                       // byte offset of the tap's first chunk in a weight row
+    s_to[tid] = (g.offy[tid] * g.SW + g.offx[tid]) * g.src_cstride;
+  }
+
+  int r_base[NA], r_y[NA], r_x[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const unsigned m = m0 + lrow + 64 * i;
+    const bool ok = m < M;
+    const unsigned mm = ok ? m : m0;
+    const int n = (int)(mm / TYX);
+    const int rem = (int)(mm - (unsigned)n * TYX);
+    const int ty = rem / g.TX, tx = rem - ty * g.TX;
+    r_y[i] = ok ? ty * g.sy : -(1 << 20);
+    r_x[i] = tx * g.sx;
+    r_base[i] = (((n - n0) * g.SH + ty * g.sy) * g.SW + tx * g.sx) * g.src_cstride;
+  }
+  int b_off[NB], b_lds[NB];          // byte offset of this thread's 16-byte piece in the split weights (or -1), in LDS
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e = tid + 256 * j;
+    const int brow = e / 6, bs = e - brow * 6;
+    const bool ok = e < BN * 6 && co0 + brow < g.Cout;
+    b_off[j] = ok ? ((co0 + brow) * wchunks) * 96 + bs * 16 : -1;
+    b_lds[j] = e < BN * 6 ? brow * X3_ROWB + bs * 16 : -1;
+  }
+  __syncthreads();
+
+  const int kch = g.K >> 4;
+  const int nch = g.ntaps * kch;
+  const int cbeg = (int)blockIdx.y * cps < nch ? (int)blockIdx.y * cps : nch;
+  const int cend = cbeg + cps < nch ? cbeg + cps : nch;
+  dst += (long long)blockIdx.y * slab_stride;
+
+  float4 rs[NA];
+  u32x4 rb[NB];
+  float lim[NA];                     // prologue: +inf where the A slot holds a real element, 0 where it is padding
+  int kc_held = 0;                   // first channel of the chunk the registers hold (prologue scale / shift lookup)
+  // the next chunk to load, advanced incrementally (tap-major, channel chunks inside a tap)
+  int ld_ch = cbeg < nch ? cbeg : nch - 1;
+  int ld_t = ld_ch / kch, ld_c0 = (ld_ch - ld_t * kch) << 4;
+  int c_oy = 0, c_ox = 0, c_wo = 0, c_to = 0, c_kc = 0;
+  auto next_chunk = [&]() {          // chunk parameters of ld_ch into c_*, then advance (stays on the last chunk)
+    c_oy = s_oy[ld_t]; c_ox = s_ox[ld_t]; c_to = s_to[ld_t];
+    c_wo = s_wo[ld_t] + (ld_c0 >> 4) * 96;
+    c_kc = ld_c0 + lcol4 * 4;
+    if (ld_ch + 1 < cend) {
+      ld_ch += 1; ld_c0 += 16;
+      if (ld_c0 >= g.K) { ld_c0 = 0; ld_t += 1; }
+    }
+  };
+  auto load_slot = [&](int sl) {
+    if (sl < NA) {
+      const int i = sl;
+      const bool ok = (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH && (unsigned)(r_x[i] + c_ox) < (unsigned)g.SW;
+      rs[i] = bld4(rsA, ok ? (unsigned)(r_base[i] + c_to + c_kc) * 4u : OOB);
+      if (has_pro) lim[i] = ok ? __builtin_inff() : 0.f;
+    } else {
+      const int j = sl - NA;
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[j] >= 0 ? (unsigned)(b_off[j] + c_wo) : OOB, 0, 0);
+    }
+  };
+  float4 p_sc = zero4(), p_sh = zero4();
+  auto store_slot = [&](auto NEG, int sl, int buf) {
+    if (sl < NA) {
+      float4 v = rs[sl];
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[sl]);
+      if (decltype(NEG)::value) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }   // odd chunks: see the main loop
+      uint2 p1, p2, p3;
+      split3_quad(v, p1, p2, p3);
+      unsigned char* q = sm + buf * A_BYTES + (lrow + 64 * sl) * X3_ROWB + lcol4 * 8;
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + 32) = p2;
+      *reinterpret_cast<uint2*>(q + 64) = p3;
+    } else {
+      const int j = sl - NA;
+      if (NB * 256 == BN * 6 || b_lds[j] >= 0)
+        *reinterpret_cast<u32x4*>(sm + 2 * A_BYTES + buf * B_BYTES + b_lds[j]) = rb[j];
+    }
+  };
+  auto load_pro = [&](int kc) { p_sc = ld4(&s_pro[kc]); p_sh = ld4(&s_pro[DCS_PRO_MAXK + kc]); };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  // Rounding bias: v_mfma_f32_32x32x16_bf16 does not round its sums to nearest -- against float64 its results sit
+  // ~0.3 mean-absolute-errors BELOW the exact value whatever their sign (v_mfma_f32_32x32x2_f32: no bias; measured by
+  // tools/conv_bias_probe.py).  A sign-independent bias survives sums over millions of pixels that cancel to almost
+  // nothing (BatchNorm bias gradients), where zero-mean rounding errors do not.  So there are two accumulator sets:
+  // even chunks add +A B to acc[0], odd chunks add (-A) B to acc[1] (the A pieces of odd chunks are negated on their
+  // way to LDS), and the tile is acc[0] - acc[1]: the hardware's downward bias enters the two halves of the sum with
+  // opposite sign and cancels.
+  f32x16 acc[2][TM][TN];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s_][a][b][r] = 0.f;
+
+  // Software pipeline as in conv_gather_kernel: registers hold chunk i+1 while chunk i is computed; each slot is written
+  // to the other LDS buffer and re-loaded with chunk i+2 between groups of MFMAs; one barrier per chunk.
+  next_chunk();
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  if (has_pro) load_pro(c_kc);
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) store_slot(P0{}, sl, 0);
+  next_chunk();
+  kc_held = c_kc;
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  __syncthreads();
+
+  // piece products, smallest first: (a1 b3), (a3 b1), (a2 b2), (a1 b2), (a2 b1), (a1 b1)
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int G = 6 * TM * TN;               // MFMAs per chunk
+  constexpr int G0 = TM * TN;                  // issued before the staging starts
+  bf16x8 fa[TM][3], fb[TN][3];
+  // iteration i (parity PAR) computes chunk cbeg + i from LDS buffer PAR into acc[PAR], writes chunk cbeg + i + 1 (in
+  // the registers; negated when i + 1 is odd) to the other buffer and re-loads the registers with chunk cbeg + i + 2
+  auto step = [&](auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    auto mfma_range = [&](int lo, int hi) {
+#pragma unroll
+      for (int q = 0; q < G; ++q) {
+        if (q < lo || q >= hi) continue;
+        const int term = q / (TM * TN), a = (q / TN) % TM, b = q % TN;
+        acc[par][a][b] =
+            __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[b][PB[term]], acc[par][a][b], 0, 0, 0);
+      }
+    };
+    const unsigned char* Ab = sm + par * A_BYTES + (wm * TM * 32 + l31) * X3_ROWB + h * 16;
+    const unsigned char* Bb = sm + 2 * A_BYTES + par * B_BYTES + (wn * TN * 32 + l31) * X3_ROWB + h * 16;
+#pragma unroll
+    for (int p = 2; p >= 0; --p) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + a * 32 * X3_ROWB + p * 32);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * X3_ROWB + p * 32);
+    }
+    mfma_range(0, G0);
+    if (has_pro) load_pro(kc_held);
+    next_chunk();
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) {
+      store_slot(std::integral_constant<int, 1 - par>{}, sl, par ^ 1);
+      load_slot(sl);
+      mfma_range(G0 + sl * (G - G0) / NSLOT, G0 + (sl + 1) * (G - G0) / NSLOT);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    kc_held = c_kc;
+    __syncthreads();
+  };
+  for (int ch = cbeg; ch < cend; ch += 2) {
+    step(P0{});
+    if (ch + 1 < cend) step(P1{});
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][a][b][r] -= acc[1][a][b][r];
+
+  conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
+                                                 mtile, M, wm, wn, bnb);
+}
+
+}  // namespace
+
+extern "C" int dcs_split_weight(const float* w, void* out, int64_t rows, int wstride, void* stream) {
+  DCS_CHECK_ARG(w && out && rows > 0 && wstride > 0 && (wstride & 15) == 0 && dcs_aligned16(w) && dcs_aligned16(out));
+  const long long n4 = (long long)rows * wstride / 4;
+  DCS_CHECK_ARG(n4 < (1ll << 31) * 256);
+  hipLaunchKernelGGL(split_weight_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, dcs_stream(stream), w,
+                     reinterpret_cast<uint2*>(out), n4, wstride);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, float* dst,
+                                  const DcsConvGeom* geom, int accumulate, float* stats, const float* pro,
+                                  const float* bn_y, const float* bn_mask, const float* bn, int relu, int nsplit,
+                                  int64_t slab_stride, void* stream) {
+  int rc = check_geom(geom);
+  if (rc != DCS_OK) return rc;
+  DCS_CHECK_ARG(src && wsplit && dst && dcs_aligned16(src) && dcs_aligned16(wsplit));
+  DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout && nsplit >= 1 && nsplit <= 64);
+  // what this kernel family covers; everything else stays on dcs_conv_gather
+  if (geom->stem || geom->Cout <= 32 || (geom->K & 15) || (geom->wstride & 15)) return DCS_E_UNSUPPORTED;
+  for (int t = 0; t < geom->ntaps; ++t)
+    if (geom->wofs[t] & 15) return DCS_E_UNSUPPORTED;
+  const long long M = (long long)geom->N * geom->TY * geom->TX;
+  DCS_CHECK_ARG(M < 0x7FFFFF00ll);
+  {
+    const long long tyx = (long long)geom->TY * geom->TX;
+    const long long img_bytes = (long long)geom->SH * geom->SW * geom->src_cstride * 4;
+    long long span = 127 / tyx + 2;
+    if (span > geom->N) span = geom->N;
+    if (span * img_bytes > 0x7FFFFFFFll || (long long)geom->Cout * geom->wstride * 6 > 0x7FFFFFFFll)
+      return DCS_E_UNSUPPORTED;
+  }
+  const BnBwdEpi bnb{bn_y, bn_mask, bn, relu};
+  DCS_CHECK_ARG(!(stats && accumulate && !bnb.y));
+  DCS_CHECK_ARG(!pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(pro)));
+  DCS_CHECK_ARG(!bnb.y || (stats && bnb.bn && nsplit == 1 && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
+                           dcs_aligned16(dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
+  if (nsplit > 1)
+    DCS_CHECK_ARG(!bias && !stats && !accumulate && slab_stride >= M * geom->dst_cstride);
+  const int bn_ = geom->Cout > 64 ? 128 : 64;
+  const int ntiles = (geom->Cout + bn_ - 1) / bn_;
+  const long long blocks = ((M + 127) / 128) * ntiles;
+  DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
+  const int nch = geom->ntaps * (geom->K >> 4);
+  // an even number of chunks per K split: every split then pairs its +A and -A chunks (the bias cancellation of the kernel)
+  int cps = (nch + nsplit - 1) / nsplit;
+  if (nsplit > 1) cps += cps & 1;
+  hipStream_t s = dcs_stream(stream);
+  const unsigned char* wsp = reinterpret_cast<const unsigned char*>(wsplit);
+  if (bn_ == 128)
+    hipLaunchKernelGGL(conv_gather_x3_kernel<128>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, wsp, bias,
+                       dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
+  else
+    hipLaunchKernelGGL(conv_gather_x3_kernel<64>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, wsp, bias,
+                       dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
+  DCS_LAUNCH_RET();
+}

@@ -192,23 +192,55 @@ def _ksplit(g, M, Cout):
     return int(max(1, min(16, 512 // blocks, nch32 // 6)))
 
 
+def x3_ok(g):
+    """Does the launch run on the split-bf16 kernels (csrc/conv_split.hip: fp32 operands as three bf16 pieces, six bf16
+    MFMAs per product, fp32-class error at 6/16 of the fp32-MFMA time)?  DCS_CONV_X3=0 keeps the exact fp32 MFMA."""
+    ok = getattr(g, "_x3", None)
+    if ok is None:
+        ok = (not g.stem and g.Cout > 32 and g.K % 16 == 0 and g.wstride % 16 == 0 and
+              all(g.wofs[t] % 16 == 0 for t in range(g.ntaps)))
+        g._x3 = ok
+    return ok and os.environ.get("DCS_CONV_X3", "1") != "0"
+
+
+def split_weight(wk):
+    """[rows, ...] fp32 (row length % 16 == 0) -> the three-piece bf16 image dcs_conv_gather_x3 stages (6 B / element)."""
+    rows = wk.shape[0]
+    ws = wk.numel() // rows
+    out = torch.empty((rows, ws * 3 // 2), device=wk.device, dtype=_F32)
+    _call("dcs_split_weight", _p(wk), _p(out), rows, ws, _stream())
+    return out
+
+
+def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None, ns=1, slab_n=0):
+    """One launch of the gather kernel family.  bnb = (y, mask, bn record, relu) or None."""
+    yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
+    if x3_ok(g):
+        _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats),
+              _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _stream())
+    elif bnb is not None:
+        assert pro is None and ns == 1
+        _call("dcs_conv_gather_bnbwd", _p(src), _p(wgt), _p(dst), C.byref(g), accumulate, _p(yb), _p(mb), _p(bnr),
+              1 if relu else 0, _p(stats), _stream())
+    elif pro is not None:
+        _call("dcs_conv_gather_pro", _p(src), _p(wgt), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats), _p(pro), ns,
+              slab_n, _stream())
+    elif ns > 1:
+        _call("dcs_conv_gather_split", _p(src), _p(wgt), _p(dst), C.byref(g), ns, slab_n, _stream())
+    else:
+        _call("dcs_conv_gather", _p(src), _p(wgt), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats), _stream())
+
+
 def _gather_split(src, wgt, g, ns, dst, accumulate, pro=None):
     """Split-K launch + fixed-order slab reduce into dst (dense [N,DH,DW,Cout])."""
     n = dst.numel()
     slab = torch.empty((ns, n), device=dst.device, dtype=_F32)
-    if pro is None:
-        _call("dcs_conv_gather_split", _p(src), _p(wgt), _p(slab), C.byref(g), ns, n, _stream())
-    else:
-        _call("dcs_conv_gather_pro", _p(src), _p(wgt), None, _p(slab), C.byref(g), 0, None, _p(pro), ns, n, _stream())
+    _gather_launch(src, wgt, None, slab, g, 0, None, pro, None, ns, n)
     _call("dcs_reduce_slab", _p(slab), _p(dst), n, ns, 1 if accumulate else 0, 0, 0, _stream())
 
 
 def _gather(src, wgt, bias, dst, g, accumulate, stats, pro):
-    if pro is None:
-        _call("dcs_conv_gather", _p(src), _p(wgt), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats), _stream())
-    else:
-        _call("dcs_conv_gather_pro", _p(src), _p(wgt), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats), _p(pro), 1, 0,
-              _stream())
+    _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro)
 
 
 def pro_ok(Cin):
@@ -292,8 +324,7 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
         for g, t in zip(gs, tiles):
             if cs != g.src_cstride:
                 g = _with_src_cs(g, cs)
-            _call("dcs_conv_gather_bnbwd", _p(dy), _p(wp), _p(out), C.byref(g), 1 if accumulate else 0, _p(yb), _p(mb), _p(bnr),
-                  1 if relu else 0, C.c_void_p(part.data_ptr() + off * 2 * Cin * 4), _stream())
+            _gather_launch(dy, wp, None, out, g, 1 if accumulate else 0, part[off:], None, (yb, mb, bnr, relu))
             off += t
         sums = torch.empty((2, Cin), device=dy.device, dtype=_F32)
         if G1 == 0:
@@ -312,7 +343,7 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
         if ns > 1:
             _gather_split(dy, wp, g, ns, out, accumulate)
         else:
-            _call("dcs_conv_gather", _p(dy), _p(wp), None, _p(out), C.byref(g), 1 if accumulate else 0, None, _stream())
+            _gather_launch(dy, wp, None, out, g, 1 if accumulate else 0, None)
     return (out, None) if bnb is not None else out
 
 

@@ -101,6 +101,19 @@ int dcs_conv_gather_pro(const float* src, const float* wgt, const float* bias, f
 int dcs_conv_wgrad_pro(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
                        int split0, int nsplit, const float* pro, void* stream);
 
+/* ---- the same gather on the bf16 matrix cores, fp32 operands as three bf16 pieces (csrc/conv_split.hip) --------------
+ * x = x1 + x2 + x3 exactly (3 x 8 significand bits); a*b is accumulated in fp32 from the six piece products >= 2^-16|ab|,
+ * the dropped three are <= 2^-24 |ab| each (below one fp32 rounding): fp32-class error at 6/16 of the fp32-MFMA time.
+ * dcs_split_weight: w [rows][wstride] (wstride % 16 == 0) -> out [rows][wstride/16][3][16] bf16 (6 bytes / element).
+ * dcs_conv_gather_x3 = dcs_conv_gather / _pro / _bnbwd / _split in one entry (pro, bn_y nullable; nsplit > 1: dst = slab,
+ * no bias / stats / accumulate) for geometries with Cout > 32, K % 16 == 0, wofs % 16 == 0, not the stem; everything
+ * else returns DCS_E_UNSUPPORTED and stays on dcs_conv_gather.  wsplit = dcs_split_weight of the fp32 weight the fp32
+ * entry would take.  Non-finite inputs give NaN (inf - inf in the split), not inf. */
+int dcs_split_weight(const float* w, void* out, int64_t rows, int wstride, void* stream);
+int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, float* dst, const DcsConvGeom* geom,
+                       int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
+                       const float* bn, int relu, int nsplit, int64_t slab_stride, void* stream);
+
 /* dw[o(i)] = (accumulate ? dw[o(i)] : 0) + sum_s slab[s][i], fixed order (deterministic).
  * row_len == 0: o(i) = i.  row_len > 0: the slab holds compact rows of row_len floats that land at stride
  * dst_stride in dw (gradient of a channel slice of a wider weight, "virtual concat" convolutions). */

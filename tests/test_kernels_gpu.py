@@ -555,6 +555,8 @@ def test_wide_channel_batchnorm_reductions(ops):
     (2, 16, 24, 64, 128, 3, 2, True, True),       # stride 2: four parity-class launches, one set of sums
     (4, 33, 47, 128, 128, 1, 1, True, True),      # skip projection (1x1) as the last writer
     (64, 96, 96, 64, 64, 3, 1, False, False),     # > 2048 row tiles: two-level final reduce
+    (4, 128, 256, 128, 128, 3, 1, False, False),  # decoder blend: 128-wide tiles, mask recomputed from y (the shape on which
+                                                  # an SLP-vectorised epilogue returned wrong odd-channel sums: csrc/Makefile)
 ])
 def test_conv_dgrad_with_batchnorm_backward_sums(ops, N, H, W, Cin, Cout, k, s, masked, acc):
     """dcs_conv_gather_bnbwd: the data gradient's epilogue also reduces sum(gm) and sum(gm * xhat) of the BatchNorm
@@ -639,3 +641,49 @@ def test_conv_with_batchnorm_relu_prologue(ops, N, H, W, Cin, Cout, k, bias, cs)
     dw_emu = cl(torch.empty(Cout, Cin, k, k))
     E.conv_wgrad(y, dy.cpu(), dw_emu, 1, pad, False, pro=bn.cpu())
     close(dw_got, dw_emu, 2e-4, "prologue weight gradient vs emulation")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s", [
+    (2, 24, 40, 64, 64, 3, 1), (1, 33, 29, 128, 128, 3, 1), (2, 16, 24, 64, 128, 3, 2), (1, 20, 36, 256, 128, 1, 1),
+    (1, 12, 16, 512, 512, 3, 1), (2, 9, 11, 128, 80, 3, 1),
+])
+def test_split_bf16_convolution_has_fp32_class_error(ops, monkeypatch, N, H, W, Cin, Cout, k, s):
+    """csrc/conv_split.hip (fp32 operands as three bf16 pieces, six bf16 MFMAs per product) against the exact-fp32 MFMA
+    kernel, both measured against a float64 convolution of the same fp32 inputs: the split kernel's error may not exceed
+    1.5x the fp32 kernel's (+ a 1e-7 floor), for the forward and the data gradient; and it must really be the one that ran
+    (the two results differ in the last bits)."""
+    pad = k // 2
+    x = rnd(N, H, W, Cin, seed=101)
+    w = cl(rnd(Cout, Cin, k, k, seed=102, scale=0.05))
+    ref = E.conv_fwd(x.double(), w.double(), s, pad)
+    xd, wd = x.to(DEV), cl(w.to(DEV))
+    g = ops.geom_fwd(N, H, W, Cin, Cout, k, k, s, pad)
+    assert ops.x3_ok(g)
+    got = ops.conv_fwd(xd, wd, s, pad).cpu()
+    monkeypatch.setenv("DCS_CONV_X3", "0")
+    f32 = ops.conv_fwd(xd, wd, s, pad).cpu()
+    monkeypatch.delenv("DCS_CONV_X3")
+    scale = float(ref.abs().max())
+    e_x3, e_32 = float((got.double() - ref).abs().max()) / scale, float((f32.double() - ref).abs().max()) / scale
+    l_x3 = float((got.double() - ref).norm() / ref.norm()); l_32 = float((f32.double() - ref).norm() / ref.norm())
+    print(f"fwd  max-rel x3 {e_x3:.3e} fp32 {e_32:.3e} | l2-rel x3 {l_x3:.3e} fp32 {l_32:.3e}")
+    assert e_x3 <= 1.5 * e_32 + 1e-7 and l_x3 <= 1.5 * l_32 + 1e-8
+    assert not torch.equal(got, f32)
+    # no rounding BIAS: the bf16 MFMA rounds its sums downwards; the kernel alternates the sign of chunk pairs so that
+    # this cancels (conv_split.hip).  Signed error sum / absolute error sum: ~N^-1/2 for zero-mean errors, -0.1..-0.3
+    # without the alternation.
+    err = got.double() - ref
+    assert abs(float(err.sum() / err.abs().sum())) < 0.03, float(err.sum() / err.abs().sum())
+    # data gradient
+    OH, OW = ref.shape[1:3]
+    dy = rnd(N, OH, OW, Cout, seed=103)
+    refd = E.conv_dgrad(dy.double(), E.pack_dgrad_weight(w.double()), (H, W), s, pad)
+    wp = ops.pack_dgrad_weight(wd)
+    gotd = ops.conv_dgrad(dy.to(DEV), wp, (H, W), s, pad).cpu()
+    monkeypatch.setenv("DCS_CONV_X3", "0")
+    f32d = ops.conv_dgrad(dy.to(DEV), wp, (H, W), s, pad).cpu()
+    monkeypatch.delenv("DCS_CONV_X3")
+    scale = float(refd.abs().max())
+    e_x3, e_32 = float((gotd.double() - refd).abs().max()) / scale, float((f32d.double() - refd).abs().max()) / scale
+    print(f"dgrad max-rel x3 {e_x3:.3e} fp32 {e_32:.3e}")
+    assert e_x3 <= 1.5 * e_32 + 1e-7
