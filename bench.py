@@ -32,6 +32,10 @@ for p in (ROOT, os.path.join(ROOT, "doubly-contrastive-semseg_amd")):
 import torch  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3
+# fp32 convolutions on the bf16 matrix cores (csrc/conv_split.hip): every fp32 multiply-add is six bf16 piece products, so
+# the speed of light of that scheme in fp32-equivalent (algorithmic) FLOP/s is the dense bf16 MFMA peak / 6
+PEAK_BF16_MFMA_TFLOPS = 2500.0
+PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
 
 
 def parse():
@@ -70,7 +74,7 @@ class ConvProfiler:
     """Records a HIP event pair (on the launch stream) around every conv launch of one kind."""
 
     GEOM_ARG = {"dcs_conv_gather": 4, "dcs_conv_gather_pro": 4, "dcs_conv_gather_x3": 4, "dcs_conv_gather_split": 3, "dcs_conv_gather_bnbwd": 3,
-                "dcs_conv_wgrad": 3, "dcs_conv_wgrad_pro": 3}      # position of the DcsConvGeom argument
+                "dcs_conv_wgrad": 3, "dcs_conv_wgrad_pro": 3, "dcs_conv_wgrad_x3": 3}   # position of the DcsConvGeom argument
 
     def __init__(self, ops):
         self.ops, self.records, self.enabled = ops, [], False
@@ -93,14 +97,14 @@ class ConvProfiler:
                 fused = name.rsplit("_", 1)[1] if name.endswith(("_pro", "_bnbwd", "_x3")) else ""
                 key = (kind + ("+" + fused if fused else ""), g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy,
                        g.stem)
-                self.records.append((kind, flops, e0, e1, key, abytes))
+                self.records.append((kind, flops, e0, e1, key, abytes, name.endswith("_x3")))
             else:
                 self._orig(name, *args)
         ops._call = wrapped
 
     def per_shape(self):
         agg = {}
-        for name, flops, e0, e1, key, _ in self.records:
+        for name, flops, e0, e1, key, _, _ in self.records:
             a = agg.setdefault(key, [0, 0.0, 0.0])
             a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += flops
         rows = []
@@ -119,10 +123,39 @@ class ConvProfiler:
                 continue
             ms = sum(r[2].elapsed_time(r[3]) for r in rs)
             fl = sum(r[1] for r in rs)
-            out[name] = dict(launches=len(rs), ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12,
+            x3 = sum(r[1] for r in rs if r[6])
+            out[name] = dict(launches=len(rs), ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12, x3_flop_share=x3 / max(fl, 1.0),
                              avg_us=ms * 1e3 / len(rs), alg_bytes_per_launch=sum(r[5] for r in rs) / len(rs),
                              alg_flops_per_launch=fl / len(rs))
         return out
+
+
+def roofline(g, wg, args, world):
+    """The dominant kernel family: the implicit-GEMM gather launches (conv forward + data gradient), all of them -- plain,
+    split-K, with fused prologue / epilogue, fp32-MFMA and split-bf16 -- timed live with HIP events.  `achieved` counts
+    ALGORITHMIC fp32 FLOPs (2 M K Cout per launch).  When most of them ran on the split-bf16 kernels the peak is the dense
+    bf16 MFMA peak / 6 (six piece products per fp32 product: 2500 / 6 = 416.7 TFLOP/s), else the fp32 MFMA peak."""
+    def peak_of(s):
+        return PEAK_X3_TFLOPS if s.get("x3_flop_share", 0.0) > 0.5 else PEAK_FP32_MFMA_TFLOPS
+    pk, pkw = peak_of(g), peak_of(wg)
+    return {"bound": "mfma", "achieved": g["tflops"], "peak": pk, "unit": "TFLOP/s", "frac": g["tflops"] / pk,
+            "peak_note": ("fp32-equivalent peak of the split-bf16 scheme = dense bf16 MFMA peak 2500 / 6 piece products"
+                          if pk == PEAK_X3_TFLOPS else "dense fp32 MFMA peak"),
+            "frac_of_fp32_mfma_peak": g["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+            "split_bf16_flop_share": g.get("x3_flop_share", 0.0),
+            "traffic": pmc_traffic(args, world),
+            "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md)",
+            "algorithmic_bytes_per_launch": g.get("alg_bytes_per_launch"),
+            "algorithmic_flops_per_launch": g.get("alg_flops_per_launch"),
+            "kernel": "conv_gather_x3_kernel / conv_gather_kernel (conv forward + data gradient; fp32 operands as three "
+                      "bf16 pieces on v_mfma_f32_32x32x16_bf16, the rest exact fp32 on v_mfma_f32_32x32x2_f32)",
+            "launches_per_step": g["launches"] // max(args.steps, 1), "avg_launch_us": g["avg_us"],
+            "ms_per_step": g["ms"] / max(args.steps, 1),
+            "wgrad_kernel": {"achieved": wg["tflops"], "peak": pkw, "frac": wg["tflops"] / pkw,
+                             "frac_of_fp32_mfma_peak": wg["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+                             "split_bf16_flop_share": wg.get("x3_flop_share", 0.0),
+                             "ms_per_step": wg["ms"] / max(args.steps, 1),
+                             "launches_per_step": wg["launches"] // max(args.steps, 1)}}
 
 
 def cpu_baseline(O, args):
@@ -152,7 +185,7 @@ def cpu_baseline(O, args):
 def pmc_traffic(args, world):
     """HBM bytes per conv_gather launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r01_h_pmc_traffic_c3.json")
+    path = os.path.join(ROOT, "profiles", "r02_a_pmc_traffic_c3.json")
     default = (args.batch, args.height, args.width, args.criterion, args.model) == \
         (16, 1024, 2048, "supcon_pixelcontrast_focal", "resnet18")
     if not (default and os.path.exists(path)):
@@ -297,17 +330,7 @@ def main():
                                                          (args.height * args.width / (1024 * 2048)) / 1e12 / world,
                        "final_loss": loss, "peak_hbm_gb": torch.cuda.max_memory_allocated() / 1e9,
                        **({"lazy_fine_feat0": bool(args.lazy_ff0)} if deeplab else {})},
-            "roofline": {"bound": "mfma", "achieved": g["tflops"], "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": g["tflops"] / PEAK_FP32_MFMA_TFLOPS, "traffic": pmc_traffic(args, world),
-                         "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_h_pmc_traffic_c3.json)",
-                         "algorithmic_bytes_per_launch": g.get("alg_bytes_per_launch"),
-                         "algorithmic_flops_per_launch": g.get("alg_flops_per_launch"),
-                         "kernel": "conv_gather_kernel (conv forward + data gradient, fp32 MFMA 32x32x2)",
-                         "launches_per_step": g["launches"] // max(args.steps, 1), "avg_launch_us": g["avg_us"],
-                         "ms_per_step": g["ms"] / max(args.steps, 1),
-                         "wgrad_kernel": {"achieved": wg["tflops"], "frac": wg["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                                          "ms_per_step": wg["ms"] / max(args.steps, 1),
-                                          "launches_per_step": wg["launches"] // max(args.steps, 1)}},
+            "roofline": roofline(g, wg, args, world),
         }
         if not args.no_similarity:
             line["similarity"] = similarity_bench(ops, dev, ts)

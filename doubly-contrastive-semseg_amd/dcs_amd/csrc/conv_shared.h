@@ -27,13 +27,12 @@ __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned byte_o
 }
 
 // BatchNorm + ReLU prologue on a staged float4: relu(v * sc + sh), or 0 where the element is padding (lim = 0; +inf on real
-// elements): two packed FMAs and four v_med3_f32 (clamp to [0, lim]) instead of fma + max + select per float.
+// elements): one fma and one v_med3_f32 (clamp to [0, lim]) per float instead of fma + max + select.  Scalar fmas on
+// purpose: packed f32 VALU ops cost ~3x their issue slot beside MFMAs (MI355X_MICROARCH.md, filler prices).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float4 pro_apply(const float4 v, const float4 sc, const float4 sh, const float lim) {
-  const f32x2 lo = __builtin_elementwise_fma(f32x2{v.x, v.y}, f32x2{sc.x, sc.y}, f32x2{sh.x, sh.y});
-  const f32x2 hi = __builtin_elementwise_fma(f32x2{v.z, v.w}, f32x2{sc.z, sc.w}, f32x2{sh.z, sh.w});
-  return make_float4(__builtin_amdgcn_fmed3f(lo.x, 0.f, lim), __builtin_amdgcn_fmed3f(lo.y, 0.f, lim),
-                     __builtin_amdgcn_fmed3f(hi.x, 0.f, lim), __builtin_amdgcn_fmed3f(hi.y, 0.f, lim));
+  return make_float4(__builtin_amdgcn_fmed3f(fmaf(v.x, sc.x, sh.x), 0.f, lim), __builtin_amdgcn_fmed3f(fmaf(v.y, sc.y, sh.y), 0.f, lim),
+                     __builtin_amdgcn_fmed3f(fmaf(v.z, sc.z, sh.z), 0.f, lim), __builtin_amdgcn_fmed3f(fmaf(v.w, sc.w, sh.w), 0.f, lim));
 }
 
 // BatchNorm-backward sums in a data-gradient epilogue (see conv_epilogue): y = the input of the BatchNorm whose

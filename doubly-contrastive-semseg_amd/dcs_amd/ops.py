@@ -371,21 +371,38 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
     Cout, Ktot, R, S = dw.shape
     g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, None, None, dil)       # compact slab rows of R*S*Cin
     M = N * g.DH * g.DW
-    if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 32 == 0:
-        tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
-        # 1024 blocks = 2 full rounds of 2 blocks per CU, but at least 8 chunks of 32 pixels per block (small inputs)
-        ns = max(1, min(-(-1024 // tiles), (M // 32) // 8))
-    else:
-        bt = 128 if (Cout > 64 and Cin > 64) else 64
-        tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
-        # 64-wide tiles run 4-5 blocks per CU: twice as many blocks (measured 70.6 -> 81.4 TF on 3x3/2 64->128)
-        ns = _nsplit(tiles, M, 2048 if bt == 64 else 1024)
     n = Cout * R * S * Cin
-    slab = torch.empty((ns, n), device=x.device, dtype=_F32)
-    if pro is None:
-        _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())
+    x3 = Cout % 4 == 0 and os.environ.get("DCS_CONV_X3", "1") != "0" and os.environ.get("DCS_WGRAD_X3", "1") != "0"
+    if x3:
+        # split-bf16 kernel (csrc/conv_split.hip): one block per (tap, 128x128 or 64x64 tile, split); an EVEN number of
+        # splits, whose rounding biases cancel pairwise in the slab reduction
+        if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 16 == 0:
+            tiles = (-(-Cout // 64)) * (-(-Cin // 64))      # nine-tap kernel: one block per 64x64 tile and split
+            ns = max(2, min(-(-1024 // tiles), (M // 16) // 16))
+        else:
+            bt = 128 if (Cout > 64 and Cin > 64) else 64
+            tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
+            ns = _nsplit(tiles, M, 2048 if bt == 64 else 1024)
+        ns += ns & 1
+        x3 = M >= 64 * ns
+    if x3:
+        slab = torch.empty((ns, n), device=x.device, dtype=_F32)
+        _call("dcs_conv_wgrad_x3", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _p(pro), _stream())
     else:
-        _call("dcs_conv_wgrad_pro", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _p(pro), _stream())
+        if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 32 == 0:
+            tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
+            # 1024 blocks = 2 full rounds of 2 blocks per CU, but at least 8 chunks of 32 pixels per block (small inputs)
+            ns = max(1, min(-(-1024 // tiles), (M // 32) // 8))
+        else:
+            bt = 128 if (Cout > 64 and Cin > 64) else 64
+            tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
+            # 64-wide tiles run 4-5 blocks per CU: twice as many blocks (measured 70.6 -> 81.4 TF on 3x3/2 64->128)
+            ns = _nsplit(tiles, M, 2048 if bt == 64 else 1024)
+        slab = torch.empty((ns, n), device=x.device, dtype=_F32)
+        if pro is None:
+            _call("dcs_conv_wgrad", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _stream())
+        else:
+            _call("dcs_conv_wgrad_pro", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _p(pro), _stream())
     if koff is None and Ktot == Cin:
         _call("dcs_reduce_slab", _p(slab), _p(krsc(dw)), n, ns, 1 if accumulate else 0, 0, 0, _stream())
     else:

@@ -114,6 +114,12 @@ int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, 
                        int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
                        const float* bn, int relu, int nsplit, int64_t slab_stride, void* stream);
 
+/* dcs_conv_wgrad / dcs_conv_wgrad_pro (pro nullable) on the bf16 matrix cores, operands as three bf16 pieces; slabs of
+ * odd split index carry the hardware's rounding bias with the opposite sign, so an EVEN nsplit cancels it in
+ * dcs_reduce_slab.  Not the stem, Cout % 4 == 0 (else DCS_E_UNSUPPORTED). */
+int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
+                      int split0, int nsplit, const float* pro, void* stream);
+
 /* dw[o(i)] = (accumulate ? dw[o(i)] : 0) + sum_s slab[s][i], fixed order (deterministic).
  * row_len == 0: o(i) = i.  row_len > 0: the slab holds compact rows of row_len floats that land at stride
  * dst_stride in dw (gradient of a channel slice of a wider weight, "virtual concat" convolutions). */

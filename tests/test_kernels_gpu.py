@@ -687,3 +687,33 @@ def test_split_bf16_convolution_has_fp32_class_error(ops, monkeypatch, N, H, W, 
     e_x3, e_32 = float((gotd.double() - refd).abs().max()) / scale, float((f32d.double() - refd).abs().max()) / scale
     print(f"dgrad max-rel x3 {e_x3:.3e} fp32 {e_32:.3e}")
     assert e_x3 <= 1.5 * e_32 + 1e-7
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s", [
+    (4, 24, 40, 64, 64, 3, 1), (2, 33, 29, 128, 128, 3, 1), (4, 16, 24, 64, 128, 3, 2), (2, 20, 36, 256, 128, 1, 1),
+    (8, 12, 16, 512, 512, 3, 1), (2, 19, 21, 128, 80, 3, 1),
+])
+def test_split_bf16_weight_gradient_has_fp32_class_error(ops, monkeypatch, N, H, W, Cin, Cout, k, s):
+    """dcs_conv_wgrad_x3 against the exact-fp32 kernels, both measured against a float64 weight gradient of the same
+    inputs: error <= 1.5x the fp32 kernel's (+ floor), no rounding bias (signed / absolute error sum), deterministic."""
+    pad = k // 2
+    x = rnd(N, H, W, Cin, seed=111)
+    OH, OW = E.conv_fwd(torch.zeros(1, H, W, Cin), cl(torch.zeros(Cout, Cin, k, k)), s, pad).shape[1:3]
+    dy = rnd(N, OH, OW, Cout, seed=112)
+    ref = cl(torch.empty(Cout, Cin, k, k, dtype=torch.float64))
+    E.conv_wgrad(x.double(), dy.double(), ref, s, pad, False)
+    xd, dyd = x.to(DEV), dy.to(DEV)
+    got, got2, f32 = (cl(torch.empty(Cout, Cin, k, k, device=DEV)) for _ in range(3))
+    ops.conv_wgrad(xd, dyd, got, s, pad, False)
+    ops.conv_wgrad(xd, dyd, got2, s, pad, False)
+    monkeypatch.setenv("DCS_CONV_X3", "0")
+    ops.conv_wgrad(xd, dyd, f32, s, pad, False)
+    monkeypatch.delenv("DCS_CONV_X3")
+    assert torch.equal(got, got2) and not torch.equal(got, f32)
+    scale = float(ref.abs().max())
+    err = got.cpu().double() - ref
+    e_x3, e_32 = float(err.abs().max()) / scale, float((f32.cpu().double() - ref).abs().max()) / scale
+    bal = float(err.sum() / err.abs().sum())
+    print(f"wgrad max-rel x3 {e_x3:.3e} fp32 {e_32:.3e} sign balance {bal:+.3f}")
+    assert e_x3 <= 1.5 * e_32 + 1e-7
+    assert abs(bal) < 0.05, bal
