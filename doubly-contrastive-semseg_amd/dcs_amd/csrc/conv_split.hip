@@ -60,19 +60,21 @@ __global__ void split_weight_kernel(const float* __restrict__ w, uint2* __restri
 
 constexpr int X3_ROWB = 112;      // bytes per LDS row
 
-template <int BN>
+template <int BN, int BM = 128>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
                            const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom g,
                            const int accumulate, const int ntiles, float* __restrict__ stats, const int cps,
                            const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro) {
-  constexpr int BM = 128, WN = 2, WM = 2, TM = 2, TN = BN / 64;
+  // 128 x 128 and 128 x 64 tiles: waves 2 x 2; 256 x 64 (64-channel layers of large maps): waves 4 x 1, so that a wave
+  // still owns a 64 x 64 sub-tile (24 MFMAs per chunk against 5-6 staging slots instead of 12 against 4)
+  constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = BM / (WM * 32), TN = BN / (WN * 32);
   constexpr int A_BYTES = BM * X3_ROWB, B_BYTES = BN * X3_ROWB;
   constexpr int SMEM_FLOATS = 2 * (A_BYTES + B_BYTES) / 4;
-  constexpr int NA = 2;                      // A slots per thread: 64 rows x 4 float4 each
+  constexpr int NA = BM / 64;                // A slots per thread: 64 rows x 4 float4 each
   constexpr int NB = (BN * 6 + 255) / 256;   // B slots per thread: 16-byte pieces of the 96-byte row images
   constexpr int NSLOT = NA + NB;
-  static_assert(BN == 128 || BN == 64, "unsupported tile");
+  static_assert((BN == 128 || BN == 64) && (BM == 128 || (BM == 256 && BN == 64)) && TM == 2, "unsupported tile");
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
   unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
@@ -674,7 +676,7 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
   {
     const long long tyx = (long long)geom->TY * geom->TX;
     const long long img_bytes = (long long)geom->SH * geom->SW * geom->src_cstride * 4;
-    long long span = 127 / tyx + 2;
+    long long span = 255 / tyx + 2;                       // images a 256-pixel block can touch
     if (span > geom->N) span = geom->N;
     if (span * img_bytes > 0x7FFFFFFFll || (long long)geom->Cout * geom->wstride * 6 > 0x7FFFFFFFll)
       return DCS_E_UNSUPPORTED;
@@ -688,7 +690,9 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
     DCS_CHECK_ARG(!bias && !stats && !accumulate && slab_stride >= M * geom->dst_cstride);
   const int bn_ = geom->Cout > 64 ? 128 : 64;
   const int ntiles = (geom->Cout + bn_ - 1) / bn_;
-  const long long blocks = ((M + 127) / 128) * ntiles;
+  // 64-wide layers of large maps: 256-pixel tiles (enough of them to fill the chip several times over)
+  const bool bm256 = bn_ == 64 && nsplit == 1 && M >= 256ll * 2048 && getenv("DCS_X3_BM128") == nullptr;
+  const long long blocks = (bm256 ? (M + 255) / 256 : (M + 127) / 128) * ntiles;
   DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
   const int nch = geom->ntaps * (geom->K >> 4);
   // an even number of chunks per K split: every split then pairs its +A and -A chunks (the bias cancellation of the kernel)
@@ -699,6 +703,9 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
   if (bn_ == 128)
     hipLaunchKernelGGL(conv_gather_x3_kernel<128>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, wsp, bias,
                        dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
+  else if (bm256)
+    hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, src, wsp, bias, dst,
+                       *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
   else
     hipLaunchKernelGGL(conv_gather_x3_kernel<64>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, wsp, bias,
                        dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
