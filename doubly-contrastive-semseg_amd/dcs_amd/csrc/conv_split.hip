@@ -60,7 +60,10 @@ __global__ void split_weight_kernel(const float* __restrict__ w, uint2* __restri
 
 constexpr int X3_ROWB = 112;      // bytes per LDS row
 
-template <int BN, int BM = 128>
+// STEM: the 7x7 / stride 2 stem on the NHWC4 image in its 14-tap form (ops.geom_stem_fwd): a tap is a filter half-row of
+// 4 pixels x 4 channels = 16 contiguous floats = exactly one chunk; lane quad q of a row is pixel q of the tap and is
+// range-checked on its own (network/backbone/resnet_pyramid.py:110-112).
+template <int BN, int BM = 128, bool STEM = false>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
                            const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom g,
@@ -87,7 +90,7 @@ void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* _
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wid / WN, wn = wid % WN;
   const int lrow = tid >> 2, lcol4 = tid & 3;
-  const bool has_pro = pro != nullptr;
+  const bool has_pro = !STEM && pro != nullptr;
   if (has_pro)
     for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
 
@@ -146,7 +149,7 @@ void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* _
   }
   __syncthreads();
 
-  const int kch = g.K >> 4;
+  const int kch = STEM ? 1 : g.K >> 4;
   const int nch = g.ntaps * kch;
   const int cbeg = (int)blockIdx.y * cps < nch ? (int)blockIdx.y * cps : nch;
   const int cend = cbeg + cps < nch ? cbeg + cps : nch;
@@ -166,13 +169,14 @@ void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* _
     c_kc = ld_c0 + lcol4 * 4;
     if (ld_ch + 1 < cend) {
       ld_ch += 1; ld_c0 += 16;
-      if (ld_c0 >= g.K) { ld_c0 = 0; ld_t += 1; }
+      if (STEM || ld_c0 >= g.K) { ld_c0 = 0; ld_t += 1; }
     }
   };
   auto load_slot = [&](int sl) {
     if (sl < NA) {
       const int i = sl;
-      const bool ok = (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH && (unsigned)(r_x[i] + c_ox) < (unsigned)g.SW;
+      const bool ok = (unsigned)(r_y[i] + c_oy) < (unsigned)g.SH &&
+                      (unsigned)(r_x[i] + c_ox + (STEM ? lcol4 : 0)) < (unsigned)g.SW;
       rs[i] = bld4(rsA, ok ? (unsigned)(r_base[i] + c_to + c_kc) * 4u : OOB);
       if (has_pro) lim[i] = ok ? __builtin_inff() : 0.f;
     } else {
@@ -668,7 +672,9 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
   DCS_CHECK_ARG(src && wsplit && dst && dcs_aligned16(src) && dcs_aligned16(wsplit));
   DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout && nsplit >= 1 && nsplit <= 64);
   // what this kernel family covers; everything else stays on dcs_conv_gather
-  if (geom->stem || geom->Cout <= 32 || (geom->K & 15) || (geom->wstride & 15)) return DCS_E_UNSUPPORTED;
+  const bool stem14 = geom->stem && geom->ntaps == 14 && geom->Cout == 64 && geom->wstride == 224 && !pro && nsplit == 1;
+  if ((geom->stem && !stem14) || geom->Cout <= 32 || (!geom->stem && (geom->K & 15)) || (geom->wstride & 15))
+    return DCS_E_UNSUPPORTED;
   for (int t = 0; t < geom->ntaps; ++t)
     if (geom->wofs[t] & 15) return DCS_E_UNSUPPORTED;
   const long long M = (long long)geom->N * geom->TY * geom->TX;
@@ -694,12 +700,21 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
   const bool bm256 = bn_ == 64 && nsplit == 1 && M >= 256ll * 2048 && getenv("DCS_X3_BM128") == nullptr;
   const long long blocks = (bm256 ? (M + 255) / 256 : (M + 127) / 128) * ntiles;
   DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
-  const int nch = geom->ntaps * (geom->K >> 4);
+  const int nch = geom->ntaps * (geom->stem ? 1 : geom->K >> 4);
   // an even number of chunks per K split: every split then pairs its +A and -A chunks (the bias cancellation of the kernel)
   int cps = (nch + nsplit - 1) / nsplit;
   if (nsplit > 1) cps += cps & 1;
   hipStream_t s = dcs_stream(stream);
   const unsigned char* wsp = reinterpret_cast<const unsigned char*>(wsplit);
+  if (geom->stem) {
+    if (bm256)
+      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256, true>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, src, wsp, bias,
+                         dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
+    else
+      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 128, true>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, src, wsp, bias,
+                         dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
+    DCS_LAUNCH_RET();
+  }
   if (bn_ == 128)
     hipLaunchKernelGGL(conv_gather_x3_kernel<128>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, wsp, bias,
                        dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);

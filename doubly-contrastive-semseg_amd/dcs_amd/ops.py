@@ -197,9 +197,14 @@ def x3_ok(g):
     MFMAs per product, fp32-class error at 6/16 of the fp32-MFMA time)?  DCS_CONV_X3=0 keeps the exact fp32 MFMA."""
     ok = getattr(g, "_x3", None)
     if ok is None:
-        ok = (not g.stem and g.Cout > 32 and g.K % 16 == 0 and g.wstride % 16 == 0 and
-              all(g.wofs[t] % 16 == 0 for t in range(g.ntaps)))
+        if g.stem:                               # the 14-tap stem geometry: a tap = one 16-float chunk
+            ok = g.ntaps == 14 and g.Cout == 64 and g.wstride == 224
+        else:
+            ok = g.Cout > 32 and g.K % 16 == 0 and g.wstride % 16 == 0
+        ok = ok and all(g.wofs[t] % 16 == 0 for t in range(g.ntaps))
         g._x3 = ok
+    if g.stem and os.environ.get("DCS_STEM_X3", "1") == "0":
+        return False
     return ok and os.environ.get("DCS_CONV_X3", "1") != "0"
 
 
@@ -429,10 +434,10 @@ def stem_conv(p, wp, want_stats=False):
     g = geom_stem_fwd(N, H, W) if os.environ.get("DCS_STEM14", "1") != "0" else geom_stem(N, H, W)
     y = torch.empty((N, g.DH, g.DW, 64), device=p.device, dtype=_F32)
     if not want_stats:
-        _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, None, _stream())
+        _gather_launch(p, wp, None, y, g, 0, None)
         return y
     part, G, G1 = _stats_buffer(N * g.DH * g.DW, 64, p.device)
-    _call("dcs_conv_gather", _p(p), _p(wp), None, _p(y), C.byref(g), 0, _p(part), _stream())
+    _gather_launch(p, wp, None, y, g, 0, part)
     return y, _stats_reduce(part, G, G1, 64, N * g.DH * g.DW)
 
 
