@@ -652,6 +652,218 @@ bool wgrad3x3_x3_eligible(const DcsConvGeom* g) {
   return g->SH == g->TY && g->SW == g->TX;
 }
 
+// ------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 convolutions (forward and data gradient) with the INPUT HALO resident in LDS: a block computes
+// TH image rows x 32 pixels x BN channels; per 16-channel chunk it stages the (TH+2) x 34-pixel halo ONCE (split into bf16
+// pieces, prologue applied) and all nine taps read it -- in the [pixel][piece][16 channels] image a tap is a row offset
+// of the fragment address.  Against conv_gather_x3_kernel that is 6x fewer activation loads, splits and LDS writes per
+// MFMA (the weights still stream per tap through a double buffer); on a power-limited chip fewer bytes moved per MFMA
+// is also clock.  Rounding-bias cancellation: chunk parity selects the accumulator set as before, but the sign now sits
+// on the WEIGHT pieces of odd chunks (sign bits flipped during the copy), because the halo serves both parities.
+template <int BN, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp, const float* __restrict__ bias,
+                       float* __restrict__ dst, const DcsConvGeom g, const int accumulate, const int ntiles,
+                       float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro) {
+  constexpr int BM = 32 * TH, HWD = 34, HROWS = (TH + 2) * HWD;
+  constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = 2, TN = BN / (WN * 32);
+  constexpr int A_BYTES = HROWS * X3_ROWB, B_BYTES = BN * X3_ROWB;
+  constexpr int SMEM_FLOATS = (A_BYTES + 2 * B_BYTES) / 4;
+  constexpr int NH = (HROWS * 4 + 255) / 256;     // halo slots per thread
+  constexpr int NB = (BN * 6 + 255) / 256;        // weight slots per thread
+  static_assert(TM * WM * 32 == BM && (BN == 64 || BN == 128), "unsupported tile");
+
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+  __shared__ long long rowoff[BM];
+  __shared__ int s_ho[9], s_wo[9];
+  __shared__ __attribute__((aligned(16))) float s_pro[2 * DCS_PRO_MAXK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int lcol4 = tid & 3;
+  const bool has_pro = pro != nullptr;
+  if (has_pro)
+    for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
+
+  const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % ntiles, mtile = bid / ntiles;
+  const int co0 = ntile * BN;
+  const int tpx = g.TX >> 5, tpy = g.TY / TH;                    // tiles per row / column of one image
+  const int n = mtile / (tpx * tpy);
+  const int trem = mtile - n * (tpx * tpy);
+  const int y0 = (trem / tpx) * TH, x0 = (trem % tpx) << 5;
+
+  if (tid < BM) {
+    const int ry = tid >> 5, px = tid & 31;
+    rowoff[tid] = (((long long)n * g.DH + (y0 + ry)) * g.DW + (x0 + px)) * g.dst_cstride;
+  }
+  if (tid < 9) {
+    s_ho[tid] = (g.offy[tid] * HWD + g.offx[tid]) * X3_ROWB;
+    s_wo[tid] = (g.wofs[tid] >> 4) * 96;
+  }
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const int wchunks = g.wstride >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n * img_elems, img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wsp), (long long)g.Cout * wchunks * 96);
+
+  int h_off[NH];                      // element offset of the halo pixel's channel quad (chunk 0) in the image, or -1
+  float lim[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int hrow = (tid + 256 * j) >> 2;
+    const int hy = hrow / HWD, hx = hrow - hy * HWD;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+    h_off[j] = ok ? (iy * g.SW + ix) * g.src_cstride + lcol4 * 4 : -1;
+    lim[j] = ok ? __builtin_inff() : 0.f;
+  }
+  int b_off[NB], b_lds[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    const int e = tid + 256 * j;
+    const int brow = e / 6, bs = e - brow * 6;
+    const bool ok = e < BN * 6 && co0 + brow < g.Cout;
+    b_off[j] = ok ? ((co0 + brow) * wchunks) * 96 + bs * 16 : -1;
+    b_lds[j] = e < BN * 6 ? brow * X3_ROWB + bs * 16 : -1;
+  }
+  __syncthreads();
+
+  const int kch = g.K >> 4;
+  const int nch = 9 * kch;
+
+  float4 rh[NH];
+  u32x4 rb[NB];
+  auto load_halo = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < NH; ++j) rh[j] = bld4(rsA, h_off[j] >= 0 ? (unsigned)(h_off[j] + kc * 16) * 4u : OOB);
+  };
+  auto store_halo = [&](int kc) {
+    float4 p_sc = zero4(), p_sh = zero4();
+    if (has_pro) { p_sc = ld4(&s_pro[kc * 16 + lcol4 * 4]); p_sh = ld4(&s_pro[DCS_PRO_MAXK + kc * 16 + lcol4 * 4]); }
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int hrow = (tid + 256 * j) >> 2;
+      if (NH * 64 != HROWS && hrow >= HROWS) continue;
+      float4 v = rh[j];
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[j]);
+      uint2 p1, p2, p3;
+      split3_quad(v, p1, p2, p3);
+      unsigned char* q = sm + hrow * X3_ROWB + lcol4 * 8;
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + 32) = p2;
+      *reinterpret_cast<uint2*>(q + 64) = p3;
+    }
+  };
+  // weights of flattened chunk i = kc * 9 + t
+  int lw_kc = 0, lw_t = 0;            // the next weight chunk to load
+  auto load_w = [&]() {
+    const int wo = s_wo[lw_t] + lw_kc * 96;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[j] >= 0 ? (unsigned)(b_off[j] + wo) : OOB, 0, 0);
+    if (lw_kc * 9 + lw_t + 1 < nch) { lw_t += 1; if (lw_t == 9) { lw_t = 0; lw_kc += 1; } }
+  };
+  auto store_w = [&](auto NEG, int buf) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      if (NB * 256 != BN * 6 && b_lds[j] < 0) continue;
+      u32x4 v = rb[j];
+      if (decltype(NEG)::value) { v.x ^= 0x80008000u; v.y ^= 0x80008000u; v.z ^= 0x80008000u; v.w ^= 0x80008000u; }
+      *reinterpret_cast<u32x4*>(sm + A_BYTES + buf * B_BYTES + b_lds[j]) = v;
+    }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  f32x16 acc[2][TM][TN];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s_][a][b][r] = 0.f;
+
+  load_halo(0);
+  load_w();
+  store_halo(0);
+  store_w(P0{}, 0);
+  load_w();                              // chunk 1
+  if (kch > 1) load_halo(1);
+  __syncthreads();
+
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+  bf16x8 fa[TM][3], fb[TN][3];
+  // fragment base of this lane: halo row of output pixel (tile row wm*2 + a, column l31) at tap offset (0, 0)
+  const unsigned char* Abase = sm + ((wm * 2 + 1) * HWD + l31 + 1) * X3_ROWB + h * 16;
+  int kc = 0, t = 0;                     // the chunk being computed
+  auto step = [&](auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    const unsigned char* Ab = Abase + s_ho[t];
+    const unsigned char* Bb = sm + A_BYTES + par * B_BYTES + (wn * TN * 32 + l31) * X3_ROWB + h * 16;
+#pragma unroll
+    for (int p = 2; p >= 0; --p) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + a * HWD * X3_ROWB + p * 32);
+#pragma unroll
+      for (int b = 0; b < TN; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * X3_ROWB + p * 32);
+    }
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[par][a][b] =
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[b][PB[term]], acc[par][a][b], 0, 0, 0);
+      if (term == 1) {                   // the next chunk's weights: registers -> the other buffer, then refill
+        store_w(std::integral_constant<int, 1 - par>{}, par ^ 1);
+        load_w();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    t += 1;
+    if (t == 9) {                        // the halo of the next 16 channels replaces this one
+      t = 0; kc += 1;
+      if (kc < kch) {
+        __syncthreads();
+        store_halo(kc);
+        if (kc + 1 < kch) load_halo(kc + 1);
+      }
+    }
+    __syncthreads();
+  };
+  for (int i = 0; i < nch; i += 2) {
+    step(P0{});
+    if (i + 1 < nch) step(P1{});
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][a][b][r] -= acc[1][a][b][r];
+
+  conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
+                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb);
+}
+
+// geometries conv3x3_x3_kernel covers: the nine taps of a dense 3x3 / stride 1 / pad 1 window in any order
+bool conv3x3_halo_eligible(const DcsConvGeom* g, int th) {
+  if (g->stem || g->ntaps != 9 || g->sy != 1 || g->sx != 1 || g->dsy != 1 || g->dsx != 1 || g->dy0 || g->dx0) return false;
+  if ((g->TX & 31) || g->TY % th || g->SH != g->TY || g->SW != g->TX || g->DH != g->TY || g->DW != g->TX) return false;
+  unsigned seen = 0;
+  for (int t = 0; t < 9; ++t) {
+    if (g->offy[t] < -1 || g->offy[t] > 1 || g->offx[t] < -1 || g->offx[t] > 1) return false;
+    seen |= 1u << ((g->offy[t] + 1) * 3 + g->offx[t] + 1);
+  }
+  return seen == 0x1FFu;
+}
+
 }  // namespace
 
 extern "C" int dcs_split_weight(const float* w, void* out, int64_t rows, int wstride, void* stream) {
@@ -706,6 +918,23 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
   if (nsplit > 1) cps += cps & 1;
   hipStream_t s = dcs_stream(stream);
   const unsigned char* wsp = reinterpret_cast<const unsigned char*>(wsplit);
+  // DCS_X3_HALO=0: never; =2: whenever the geometry allows (tests: small shapes); default: when there are enough tiles
+  const char* halo_env = getenv("DCS_X3_HALO");                  // read per launch: the tests flip it
+  const bool g_halo = halo_env == nullptr || halo_env[0] != '0';
+  const bool g_halo_force = halo_env != nullptr && halo_env[0] == '2';
+  if (g_halo && nsplit == 1 && (long long)geom->SH * geom->SW * geom->src_cstride * 4 <= 0x7FFFFFFFll) {
+    // enough tiles to fill the chip twice over, else the per-tap kernel (and its K splits) does better
+    if (bn_ == 64 && conv3x3_halo_eligible(geom, 8) && (g_halo_force || M >= 256ll * 1024)) {
+      hipLaunchKernelGGL((conv3x3_x3_kernel<64, 8>), dim3((unsigned)((M / 256) * ntiles)), dim3(256), 0, s, src, wsp, bias, dst,
+                         *geom, accumulate, ntiles, stats, bnb, pro);
+      DCS_LAUNCH_RET();
+    }
+    if (bn_ == 128 && conv3x3_halo_eligible(geom, 4) && (g_halo_force || (M / 128) * ntiles >= 1024)) {
+      hipLaunchKernelGGL((conv3x3_x3_kernel<128, 4>), dim3((unsigned)((M / 128) * ntiles)), dim3(256), 0, s, src, wsp, bias, dst,
+                         *geom, accumulate, ntiles, stats, bnb, pro);
+      DCS_LAUNCH_RET();
+    }
+  }
   if (geom->stem) {
     if (bm256)
       hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256, true>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, src, wsp, bias,

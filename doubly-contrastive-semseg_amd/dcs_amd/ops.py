@@ -208,12 +208,28 @@ def x3_ok(g):
     return ok and os.environ.get("DCS_CONV_X3", "1") != "0"
 
 
+_split_cache = {}
+
+
+def new_step():
+    """Weights may change between steps (optimizer): forget the split images of the previous step.  Called at the start of
+    every model forward; within one forward + backward a weight (or its data-gradient repack) is split once and reused
+    by the three pyramid levels."""
+    _split_cache.clear()
+
+
 def split_weight(wk):
-    """[rows, ...] fp32 (row length % 16 == 0) -> the three-piece bf16 image dcs_conv_gather_x3 stages (6 B / element)."""
+    """[rows, ...] fp32 (row length % 16 == 0) -> the three-piece bf16 image dcs_conv_gather_x3 stages (6 B / element).
+    Cached per step by storage address; the cache entry keeps ``wk`` alive, so the address cannot be recycled."""
+    key = (wk.data_ptr(), tuple(wk.shape), tuple(wk.stride()))
+    hit = _split_cache.get(key)
+    if hit is not None:
+        return hit[1]
     rows = wk.shape[0]
     ws = wk.numel() // rows
     out = torch.empty((rows, ws * 3 // 2), device=wk.device, dtype=_F32)
     _call("dcs_split_weight", _p(wk), _p(out), rows, ws, _stream())
+    _split_cache[key] = (wk, out)
     return out
 
 

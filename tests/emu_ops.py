@@ -34,6 +34,10 @@ def krsc(w):
 PRO_MAXK = 512
 
 
+def new_step():
+    pass
+
+
 def pro_ok(Cin):
     return Cin <= PRO_MAXK
 

@@ -61,32 +61,52 @@ def _argmax_budget(bud, seg, g, g64):
 
 
 @pytest.mark.parametrize("lazy", [False, True])
-def test_deeplab_step_matches_reference_golden(golden_dir, lazy):
+def test_deeplab_step_matches_reference_golden(golden_dir, lazy, monkeypatch):
+    """The anchors are sampled from the argmax-derived hard / easy split of the 1/4-resolution predictions; on this
+    101-layer fixture ~0.3 % of the argmax decisions are near-ties that flip between two fp32 evaluations (the reference's
+    own fp32 and fp64 runs disagree on 131 pixels), so the sampled pixels are only reproducible for ONE rounding of the
+    forward pass.  The forward-output budgets are always applied to the default (split-bf16) run; the anchor-dependent
+    part (losses, gradients) is applied to that run when it drew the reference's anchors and otherwise to a run with the
+    exact-fp32 MFMA kernels (DCS_CONV_X3=0) -- which must then draw them."""
     g = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.npz"), allow_pickle=False)
     g64 = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.f64.npz"), allow_pickle=False)
     e32 = lambda k: g64["e32::" + k]
     b = 2
     img, labels, ldw, weather, cw = O.synthetic_batch(b, 128, 256, seed=51, two_crops=True, cell=32)
-    ts = build(b, cw, lazy=lazy)
-    s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
-    torch.manual_seed(321)
-    out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
     bud = Budget(f"gpu_deeplab_step_b2_128x256_lazy{int(lazy)}")
-    # the very pixels the reference's sampler drew (identical argmax-derived hard/easy split and RNG consumption)
-    img_i, cls, pix, n_view = ts.pixelcontrast_criterion.last_anchors
-    assert np.array_equal(np.asarray(img_i), g["anchor_img"]) and np.array_equal(pix.cpu().numpy().T.astype(np.int32), g["anchor_pix"])
+
+    def run():
+        ts_ = build(b, cw, lazy=lazy)
+        s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        torch.manual_seed(321)
+        out_ = ts_.step((s0, dict(left=img[b:])), do_optimizer_step=False)
+        img_i, cls, pix, n_view = ts_.pixelcontrast_criterion.last_anchors
+        same = np.array_equal(np.asarray(img_i), g["anchor_img"]) and \
+            np.array_equal(pix.cpu().numpy().T.astype(np.int32), g["anchor_pix"])
+        return ts_, out_, same
+
+    def forward_budgets(out_, tag):
+        bud.check(tag + "before", out_["left_seg_beforeup"], g["before"], g64["before"], metric=rel_max, e32=float(e32("before")))
+        bud.check(tag + "fine_feat", out_["fine_feat"][:, ::8], g["fine_feat_sub"], g64["fine_feat_sub"], metric=rel_max,
+                  e32=float(e32("fine_feat_sub")))
+        bud.check(tag + "seg logits", out_["left_seg"][:, :, ::4, ::4], g["seg_logits_sub"], g64["seg_logits_sub"],
+                  metric=rel_max, e32=float(e32("seg_logits_sub")))
+        _argmax_budget(bud, out_["left_seg"], g, g64)
+
+    ts, out, same = run()
+    forward_budgets(out, "")
+    bud.note("anchors", split_bf16_run_drew_the_reference_anchors=bool(same))
+    if not same:
+        monkeypatch.setenv("DCS_CONV_X3", "0")
+        ts, out, same = run()
+        assert same, "the exact-fp32 run must draw the very pixels the reference's sampler drew"
+        forward_budgets(out, "fp32 kernels: ")
     # losses as in tests/step_check.py: held to the north-star tolerance (1e-3) against the float64 anchor, and the ratio
     # to the reference's own fp32 error is recorded (one scalar is one draw of a heavy-tailed ratio: no K bound on it)
     for k in ("total", "supcon", "pixel", "seg"):
         err = abs(float(out[k].detach()) - float(g64[k])) / abs(float(g64[k]))
         bud.check_abs("loss " + k, err, 1e-3)
         bud.note("loss " + k, err_hip=err, err_ref32=max(float(e32(k)), abs(float(g[k]) - float(g64[k])) / abs(float(g64[k]))))
-    bud.check("before", out["left_seg_beforeup"], g["before"], g64["before"], metric=rel_max, e32=float(e32("before")))
-    bud.check("fine_feat", out["fine_feat"][:, ::8], g["fine_feat_sub"], g64["fine_feat_sub"], metric=rel_max,
-              e32=float(e32("fine_feat_sub")))
-    bud.check("seg logits", out["left_seg"][:, :, ::4, ::4], g["seg_logits_sub"], g64["seg_logits_sub"], metric=rel_max,
-              e32=float(e32("seg_logits_sub")))
-    _argmax_budget(bud, out["left_seg"], g, g64)
     params = dict(ts.model.named_parameters())
     names = [str(s) for s in g["grad_names"]]
     e32n = e32("grad_norms")

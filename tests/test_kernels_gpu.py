@@ -717,3 +717,42 @@ def test_split_bf16_weight_gradient_has_fp32_class_error(ops, monkeypatch, N, H,
     print(f"wgrad max-rel x3 {e_x3:.3e} fp32 {e_32:.3e} sign balance {bal:+.3f}")
     assert e_x3 <= 1.5 * e_32 + 1e-7
     assert abs(bal) < 0.05, bal
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [
+    (2, 16, 64, 64, 64), (1, 8, 32, 64, 64), (3, 24, 32, 48, 64), (2, 16, 64, 64, 48),      # 8 x 32-pixel tiles, 64 channels wide
+    (16, 16, 64, 128, 128), (8, 12, 96, 256, 128), (8, 8, 64, 128, 256),                    # 4 x 32-pixel tiles, 128 wide
+])
+def test_split_bf16_convolution_with_resident_halo(ops, monkeypatch, N, H, W, Cin, Cout):
+    """conv3x3_x3_kernel (input halo resident in LDS, nine taps per staged chunk) forced on small maps (DCS_X3_HALO=2)
+    against the per-tap split-bf16 kernel (DCS_X3_HALO=0) and float64: forward with statistics, BatchNorm + ReLU prologue
+    (bitwise equal to the materialised activation), data gradient accumulating into a tensor with the BatchNorm-backward
+    sums; deterministic; fp32-class error without bias."""
+    monkeypatch.setenv("DCS_KSPLIT", "0")                 # the halo kernel has no K splits
+    x = rnd(N, H, W, Cin, seed=121)
+    w = cl(rnd(Cout, Cin, 3, 3, seed=122, scale=0.05))
+    ref = E.conv_fwd(x.double(), w.double(), 1, 1)
+    xd, wd = x.to(DEV), cl(w.to(DEV))
+    gam, bet = (rnd(Cin, seed=123) * 0.1 + 1).to(DEV), (rnd(Cin, seed=124) * 0.1).to(DEV)
+    bn = ops.bn_finalize(ops.colsum(xd.reshape(-1, Cin), moments=True), gam, bet, torch.zeros(Cin, device=DEV),
+                         torch.ones(Cin, device=DEV), N * H * W, True)
+    dy = rnd(N, H, W, Cout, seed=125).to(DEV)
+    base = rnd(N, H, W, Cin, seed=126).to(DEV)
+    wp = ops.pack_dgrad_weight(wd)
+    res = {}
+    for mode in ("2", "0"):
+        monkeypatch.setenv("DCS_X3_HALO", mode)
+        y, st = ops.conv_fwd(xd, wd, 1, 1, want_stats=True)
+        y2, st2 = ops.conv_fwd(xd, wd, 1, 1, want_stats=True)
+        assert torch.equal(y, y2) and torch.equal(st, st2)
+        yp = ops.conv_fwd(xd, wd, 1, 1, pro=bn)
+        assert torch.equal(yp, ops.conv_fwd(ops.bn_act(xd, bn, relu=True), wd, 1, 1))
+        d, sums = ops.conv_dgrad(dy, wp, (H, W), 1, 1, out=base.clone(), accumulate=True, bnb=(xd, None, bn, True))
+        res[mode] = (y.cpu(), st.cpu(), d.cpu(), sums.cpu())
+    (ya, sa, da, qa), (yb, sb, db, qb) = res["2"], res["0"]
+    assert not torch.equal(ya, yb)                        # two different kernels really ran
+    scale = float(ref.abs().max())
+    ea, eb = ya.double() - ref, yb.double() - ref
+    assert float(ea.abs().max()) / scale <= 1.5 * float(eb.abs().max()) / scale + 1e-7
+    assert abs(float(ea.sum() / ea.abs().sum())) < 0.03
+    close(sa, sb, 2e-5, "batch statistics"); close(da, db, 2e-5, "data gradient"); close(qa, qb, 2e-5, "BatchNorm-backward sums")
