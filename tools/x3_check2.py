@@ -1,3 +1,8 @@
+#!/usr/bin/env python3
+"""Per-tile BatchNorm-backward partial sums of a data-gradient launch (dcs_conv_gather_x3 / dcs_conv_gather_bnbwd through
+ops._gather_launch) against sums recomputed from the written gradient: determinism, unwritten rows, wrong entries.  This is
+the probe that isolated the SLP-vectorised epilogue defect described in csrc/Makefile (5 % of the odd-channel entries wrong
+and different from run to run on the 128-wide split-bf16 tile; exact with -fno-slp-vectorize)."""
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "doubly-contrastive-semseg_amd")):
