@@ -513,8 +513,7 @@ def _plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=10
                 num_hard_keep = num_hard
                 num_easy_keep = n_view - num_hard_keep
             else:
-                print("this shoud be never touched! {} {} {}".format(num_hard, num_easy, n_view))
-                raise Exception
+                raise Exception(f"class with fewer than n_view/2 hard and easy pixels: {num_hard} {num_easy} {n_view}")
             perm = randperm(num_hard)                      # consumed even when nothing is kept, like the reference
             if num_hard_keep > 0:
                 for r in perm[:num_hard_keep].tolist():

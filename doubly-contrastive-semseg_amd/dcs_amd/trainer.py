@@ -206,18 +206,21 @@ class TrainStep:
             out["seg"] = self.criterion(left_seg, labels, sample)
             total = out["simclr"] * 1 / o.batch_size + out["seg"] * 1.2
         elif crit == "pixelcontrast_focal":
-            out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
+            # The sampler's host half (the reference's CPU randperm stream, ~6 ms at C3) runs while the device works on
+            # everything that does not need the anchors: the counting kernel + D2H copy were queued by prefetch() above
+            # (on the labels BEFORE the focal loss rewrites 255 -> 0), so the segmentation loss goes first.
             out["seg"] = self.criterion(left_seg, labels, sample)
+            out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
             total = out["pixel"] * 1 / o.batch_size + out["seg"] * 1.2
         elif crit == "supcon_pixelcontrast_focal":
             out["supcon"] = self.supcon_criterion(fine_feat, class_labels=gt_weather, mask=None)
+            out["seg"] = self.criterion(left_seg, labels, sample)          # before the pixel loss: see pixelcontrast_focal
             out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
-            out["seg"] = self.criterion(left_seg, labels, sample)
             total = 1 / o.batch_size * (out["supcon"] + out["pixel"]) + out["seg"] * 1.2
         elif crit == "supcon_simclr_pixelcontrast_focal":
             out["simclr"] = self.supcon_criterion(fine_feat, class_labels=None, mask=None)
-            out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
             out["seg"] = self.criterion(left_seg, labels, sample)
+            out["pixel"] = self.pixelcontrast_criterion(fine_feat0, labels=labels, predict=left_seg_beforeup)
             total = 1 / o.batch_size * (out["simclr"] + out["pixel"]) + out["seg"] * 1.2
         elif crit == "crossentropy":
             out["ce"] = self.ce_criterion(left_seg, labels)
