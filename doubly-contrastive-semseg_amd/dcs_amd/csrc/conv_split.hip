@@ -645,6 +645,177 @@ void conv_wgrad3x3_x3_kernel(const float* __restrict__ src, const float* __restr
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// weight gradient of the 7x7 / stride 2 / pad 3 stem on the bf16 matrix cores (split-bf16 counterpart of
+// stem_wgrad_kernel): all seven filter rows per block, a chunk = 16 consecutive output pixels of one output row.  dy is
+// staged as [pixel][piece][64 channels]; the 7 x 38-pixel input patch as one contiguous bf16 run per (filter row, piece).
+// The im2col row of output pixel p for filter row r is patch[r][8p .. 8p+31] (7 px x 4 ch + one pad pixel whose products
+// land in the padded weight slots): for the transposing read that is a "matrix" whose rows (pixels) are 16 bytes apart --
+// every lane of a 16-lane group supplies its own address, so the Toeplitz structure needs no im2col copy here either.
+// Wave w owns filter rows 2w, 2w+1 (row 7 does not exist) x both 32-channel output tiles.  Odd splits: (-dy), negated
+// output (rounding-bias cancellation, see conv_wgrad_x3_kernel).
+__global__ __launch_bounds__(256, 2)
+void stem_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                          const DcsConvGeom g, const int dy_cstride, const int split0, const int cps) {
+  constexpr int CHP = 16, PWP = 38;                    // pixels per chunk, patch width in pixels
+  constexpr int PIECE = 128, ROW = 3 * PIECE + 64;     // dy image: 448-byte rows
+  constexpr int PL = PWP * 8;                          // bytes of one (filter row, piece) run: 38 px x 4 ch x 2 B = 304
+  constexpr int DB = CHP * ROW, PB = 7 * 3 * PL;
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * DB + 2 * PB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int lcol4 = tid & 15, lrow = tid >> 4;
+  const int split = blockIdx.x;
+  const bool odd = ((split0 + split) & 1) != 0;
+  const int cpr = g.TX / CHP;
+  const int nchunks_total = g.N * g.TY * cpr;
+  const int cbeg = split * cps;
+  const int cend = cbeg + cps < nchunks_total ? cbeg + cps : nchunks_total;
+  const int nch = cend > cbeg ? cend - cbeg : 0;
+
+  int q_n, q_ty, q_tx;
+  {
+    const int c = cbeg < nchunks_total ? cbeg : 0;
+    const int per_img = g.TY * cpr;
+    q_n = c / per_img;
+    const int rem = c - q_n * per_img;
+    q_ty = rem / cpr;
+    q_tx = (rem - q_ty * cpr) * CHP;
+  }
+  const int n0 = q_n;
+  const long long img_elems = (long long)g.SH * g.SW * 4;
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
+  const long long mbeg = (long long)cbeg * CHP;
+  const __amdgpu_buffer_rsrc_t rsD = make_rsrc(dy + mbeg * dy_cstride, (long long)nch * CHP * dy_cstride * 4);
+
+  int ps_r[2], ps_c[2];
+  bool ps_ok[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int e = tid + 256 * k;
+    ps_ok[k] = e < 7 * PWP;
+    ps_r[k] = e / PWP;
+    ps_c[k] = e - ps_r[k] * PWP;
+  }
+
+  float4 rs[3];
+  int l_chunk = 0;
+  auto load_slot = [&](int sl) {
+    if (sl == 0) {
+      const int mr = l_chunk * CHP + lrow;
+      rs[0] = bld4(rsD, (unsigned)(mr * dy_cstride + lcol4 * 4) * 4u);
+    } else {
+      const int k = sl - 1;
+      const int iy = 2 * q_ty - 3 + ps_r[k], ix = 2 * q_tx - 3 + ps_c[k];
+      const bool ok = ps_ok[k] && l_chunk < nch && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+      rs[sl] = bld4(rsX, ok ? (unsigned)((((q_n - n0) * g.SH + iy) * g.SW + ix) * 4) * 4u : OOB);
+    }
+  };
+  auto advance_chunk = [&]() {
+    l_chunk += 1;
+    q_tx += CHP;
+    if (q_tx >= g.TX) { q_tx = 0; q_ty += 1; }
+    if (q_ty >= g.TY) { q_ty = 0; q_n += 1; }
+  };
+  auto store_slot = [&](int sl, int buf) {
+    float4 v = rs[sl];
+    unsigned char* q;
+    int pstride;
+    if (sl == 0) {
+      if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
+      q = sm + buf * DB + lrow * ROW + lcol4 * 8;
+      pstride = PIECE;
+    } else {
+      const int k = sl - 1;
+      if (!ps_ok[k]) return;
+      q = sm + 2 * DB + buf * PB + ps_r[k] * 3 * PL + ps_c[k] * 8;
+      pstride = PL;
+    }
+    uint2 p1, p2, p3;
+    split3_quad(v, p1, p2, p3);
+    *reinterpret_cast<uint2*>(q) = p1;
+    *reinterpret_cast<uint2*>(q + pstride) = p2;
+    *reinterpret_cast<uint2*>(q + 2 * pstride) = p3;
+  };
+
+  f32x16 acc[2][2];                         // [filter row 2w + a][output-channel tile]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) load_slot(sl);
+  advance_chunk();
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) store_slot(sl, 0);
+#pragma unroll
+  for (int sl = 0; sl < 3; ++sl) load_slot(sl);
+  advance_chunk();
+  __syncthreads();
+
+  const int tj = lane & 15;
+  const int prow = 8 * h + (tj >> 2);                               // pixel (k) row this lane addresses, + 4 for the 2nd read
+  const int ccol = 16 * ((lane >> 4) & 1) + 4 * (tj & 3);            // first of its four columns
+  const int d_off = prow * ROW + ccol * 2;
+  const int p_off = (8 * prow + ccol) * 2;
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PBt[6] = {2, 0, 1, 1, 0, 0};
+  auto frag = [&](const unsigned char* base, int second) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + second));
+    const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  const int r0 = 2 * wid;
+  const bool two = r0 + 1 < 7;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    const unsigned char* Db = sm + buf * DB + d_off;
+    const unsigned char* Pb = sm + 2 * DB + buf * PB + p_off;
+    bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) fa[b][p] = frag(Db + p * PIECE + b * 64, 4 * ROW);
+      fb[0][p] = frag(Pb + (r0 * 3 + p) * PL, 64);                    // 4 pixels further = 4 x 16 bytes
+      fb[1][p] = frag(Pb + ((two ? r0 + 1 : r0) * 3 + p) * PL, 64);
+    }
+#pragma unroll
+    for (int term = 0; term < 6; ++term) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][PA[term]], fb[0][PBt[term]], acc[0][b], 0, 0, 0);
+        if (two) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][PA[term]], fb[1][PBt[term]], acc[1][b], 0, 0, 0);
+      }
+      if (term < 3) {
+        store_slot(term, buf ^ 1);
+        load_slot(term);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    advance_chunk();
+    __syncthreads();
+  }
+
+  float* out = slab + (long long)(split0 + split) * g.Cout * g.wstride;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
+    const int r = r0 + a;
+    if (r >= 7) continue;
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int co = b * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
+        out[(long long)co * g.wstride + r * 32 + l31] = odd ? -acc[a][b][q] : acc[a][b][q];
+      }
+  }
+}
+
 bool wgrad3x3_x3_eligible(const DcsConvGeom* g) {
   if (g->stem || g->ntaps != 9 || g->sy != 1 || g->sx != 1 || (g->TX & 15) != 0 || g->wstride != 9 * g->K) return false;
   for (int t = 0; t < 9; ++t)
@@ -964,7 +1135,17 @@ extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab,
   DCS_CHECK_ARG((dy_cstride & 3) == 0 && dy_cstride >= geom->Cout && nsplit > 0 && split0 >= 0);
   DCS_CHECK_ARG(geom->dsy == 1 && geom->dsx == 1 && geom->dy0 == 0 && geom->dx0 == 0 &&
                 geom->TY == geom->DH && geom->TX == geom->DW);
-  if (geom->stem || (geom->Cout & 3)) return DCS_E_UNSUPPORTED;
+  if (geom->stem) {                    // the seven-tap stem geometry (ops.geom_stem): its own kernel
+    if ((geom->TX & 15) || geom->Cout != 64 || geom->wstride != 224 || geom->ntaps != 7 || pro) return DCS_E_UNSUPPORTED;
+    const long long nchunks = (long long)geom->N * geom->TY * (geom->TX / 16);
+    const int cps = (int)((nchunks + nsplit - 1) / nsplit);
+    const long long span = ((long long)cps * 32 + 8ll * geom->SW) * 16;
+    if ((long long)cps * 16 * dy_cstride * 4 >= 0x7FFFFFFFll || span >= 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
+    hipLaunchKernelGGL(stem_wgrad_x3_kernel, dim3((unsigned)nsplit), dim3(256), 0, dcs_stream(stream), src, dy, slab, *geom,
+                       dy_cstride, split0, cps);
+    DCS_LAUNCH_RET();
+  }
+  if (geom->Cout & 3) return DCS_E_UNSUPPORTED;
   const long long M = (long long)geom->N * geom->TY * geom->TX;
   long long mps = (M + nsplit - 1) / nsplit;
   mps = (mps + 31) / 32 * 32;

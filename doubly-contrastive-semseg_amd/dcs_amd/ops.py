@@ -462,6 +462,14 @@ def stem_wgrad(p, dy, dwp, accumulate):
     N, H, W, _ = p.shape
     g = geom_stem(N, H, W)
     M = N * g.DH * g.DW
+    x3 = g.DW % 16 == 0 and M >= 256 and os.environ.get("DCS_CONV_X3", "1") != "0" and os.environ.get("DCS_STEM_X3", "1") != "0"
+    if x3:                                     # split-bf16 stem kernel: an even number of splits (bias cancellation)
+        ns = max(2, min(512, M // 64))
+        ns += ns & 1
+        slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
+        _call("dcs_conv_wgrad_x3", _p(p), _p(dy), _p(slab), C.byref(g), 64, 0, ns, None, _stream())
+        _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, 0, 0, _stream())
+        return
     ns = max(1, min(512, M // 64)) if g.DW % 32 == 0 else _nsplit(7, M)   # seven-row stem kernel: one block per split
     slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
     _call("dcs_conv_wgrad", _p(p), _p(dy), _p(slab), C.byref(g), 64, 0, ns, _stream())
