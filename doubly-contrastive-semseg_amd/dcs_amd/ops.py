@@ -229,6 +229,8 @@ def split_weight(wk):
     ws = wk.numel() // rows
     out = torch.empty((rows, ws * 3 // 2), device=wk.device, dtype=_F32)
     _call("dcs_split_weight", _p(wk), _p(out), rows, ws, _stream())
+    if len(_split_cache) >= 1024:            # callers that never run a model forward (micro-benchmarks, tests)
+        _split_cache.clear()
     _split_cache[key] = (wk, out)
     return out
 
