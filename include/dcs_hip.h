@@ -106,8 +106,11 @@ int dcs_conv_wgrad_pro(const float* src, const float* dy, float* slab, const Dcs
  * the dropped three are <= 2^-24 |ab| each (below one fp32 rounding): fp32-class error at 6/16 of the fp32-MFMA time.
  * dcs_split_weight: w [rows][wstride] (wstride % 16 == 0) -> out [rows][wstride/16][3][16] bf16 (6 bytes / element).
  * dcs_conv_gather_x3 = dcs_conv_gather / _pro / _bnbwd / _split in one entry (pro, bn_y nullable; nsplit > 1: dst = slab,
- * no bias / stats / accumulate) for geometries with Cout > 32, K % 16 == 0, wofs % 16 == 0, not the stem; everything
- * else returns DCS_E_UNSUPPORTED and stays on dcs_conv_gather.  wsplit = dcs_split_weight of the fp32 weight the fp32
+ * no bias / stats / accumulate) for geometries with Cout > 32, K % 16 == 0, wofs % 16 == 0, and for the stem in its 14-tap
+ * form (a tap = a filter half-row of 4 px x 4 ch = one 16-float chunk; Cout 64, wstride 224, no prologue / K split);
+ * everything else returns DCS_E_UNSUPPORTED and stays on dcs_conv_gather.  Dense 3x3 / stride 1 / pad 1 geometries on
+ * maps with TX % 32 == 0 and enough tiles run the variant that keeps the input halo resident in LDS (DCS_X3_HALO=0: never,
+ * =2: whenever the geometry allows).  wsplit = dcs_split_weight of the fp32 weight the fp32
  * entry would take.  Non-finite inputs give NaN (inf - inf in the split), not inf. */
 int dcs_split_weight(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, float* dst, const DcsConvGeom* geom,
@@ -116,7 +119,8 @@ int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, 
 
 /* dcs_conv_wgrad / dcs_conv_wgrad_pro (pro nullable) on the bf16 matrix cores, operands as three bf16 pieces; slabs of
  * odd split index carry the hardware's rounding bias with the opposite sign, so an EVEN nsplit cancels it in
- * dcs_reduce_slab.  Not the stem, Cout % 4 == 0 (else DCS_E_UNSUPPORTED). */
+ * dcs_reduce_slab.  Cout % 4 == 0; the stem in its seven-tap form with TX % 16 == 0, Cout 64, wstride 224, no prologue
+ * (else DCS_E_UNSUPPORTED). */
 int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
                       int split0, int nsplit, const float* pro, void* stream);
 
