@@ -73,7 +73,7 @@ def device_batch(O, b, h, w, seed, two, dev):
 class ConvProfiler:
     """Records a HIP event pair (on the launch stream) around every conv launch of one kind."""
 
-    GEOM_ARG = {"dcs_conv_gather": 4, "dcs_conv_gather_pro": 4, "dcs_conv_gather_x3": 4, "dcs_conv_gather_split": 3, "dcs_conv_gather_bnbwd": 3,
+    GEOM_ARG = {"dcs_conv_gather": 4, "dcs_conv_gather_pro": 4, "dcs_conv_gather_x3": 4, "dcs_conv3x3_x3w": 4, "dcs_conv_gather_split": 3, "dcs_conv_gather_bnbwd": 3,
                 "dcs_conv_wgrad": 3, "dcs_conv_wgrad_pro": 3, "dcs_conv_wgrad_x3": 3}   # position of the DcsConvGeom argument
 
     def __init__(self, ops):
@@ -94,10 +94,10 @@ class ConvProfiler:
                 self._orig(name, *args)
                 e1.record()
                 kind = "dcs_conv_wgrad" if name.startswith("dcs_conv_wgrad") else "dcs_conv_gather"
-                fused = name.rsplit("_", 1)[1] if name.endswith(("_pro", "_bnbwd", "_x3")) else ""
+                fused = name.rsplit("_", 1)[1] if name.endswith(("_pro", "_bnbwd", "_x3", "_x3w")) else ""
                 key = (kind + ("+" + fused if fused else ""), g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy,
                        g.stem)
-                self.records.append((kind, flops, e0, e1, key, abytes, name.endswith("_x3")))
+                self.records.append((kind, flops, e0, e1, key, abytes, name.endswith(("_x3", "_x3w"))))
             else:
                 self._orig(name, *args)
         ops._call = wrapped

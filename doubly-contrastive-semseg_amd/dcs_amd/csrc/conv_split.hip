@@ -1023,6 +1023,213 @@ void conv3x3_x3_kernel(const float* __restrict__ src, const unsigned char* __res
                                                  mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb);
 }
 
+// ------------------------------------------------------------------------------------------------
+// conv3x3_x3_kernel with the WEIGHT fragments straight from global memory (no LDS staging of weights, no per-tap barrier):
+// dcs_split_weight_frag lays the split weights out fragment-major -- for K chunk c, 32-row tile j, piece p the 64 lanes'
+// 16-byte MFMA B fragments are 1 KiB contiguous -- followed by a second copy with the sign bits flipped (odd chunks read
+// that one: rounding-bias cancellation as in conv3x3_x3_kernel, no XOR in the kernel).  A wave loads the fragments of
+// the NEXT tap while it multiplies the current one; the halo is the only LDS tenant, so barriers remain only around its
+// replacement every nine taps.
+template <int BN, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_x3w_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
+                        float* __restrict__ dst, const DcsConvGeom g, const int accumulate, const int ntiles,
+                        float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
+                        const unsigned neg_off) {
+  constexpr int BM = 32 * TH, HWD = 34, HROWS = (TH + 2) * HWD;
+  constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = 2, TN = BN / (WN * 32);
+  constexpr int A_BYTES = HROWS * X3_ROWB;
+  constexpr int EPI_FLOATS = 4 * 32 * (TN * 32 + 4) + WM * BN * 2;
+  constexpr int SMEM_FLOATS = (A_BYTES / 4) > EPI_FLOATS ? (A_BYTES / 4) : EPI_FLOATS;
+  constexpr int NH = (HROWS * 4 + 255) / 256;
+  static_assert(TM * WM * 32 == BM && (BN == 64 || BN == 128), "unsupported tile");
+
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+  __shared__ long long rowoff[BM];
+  __shared__ int s_ho[9], s_wc[9];
+  __shared__ __attribute__((aligned(16))) float s_pro[2 * DCS_PRO_MAXK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int lcol4 = tid & 3;
+  const bool has_pro = pro != nullptr;
+  if (has_pro)
+    for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
+
+  const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
+  const int ntile = bid % ntiles, mtile = bid / ntiles;
+  const int co0 = ntile * BN;
+  const int tpx = g.TX >> 5, tpy = g.TY / TH;
+  const int n = mtile / (tpx * tpy);
+  const int trem = mtile - n * (tpx * tpy);
+  const int y0 = (trem / tpx) * TH, x0 = (trem % tpx) << 5;
+
+  if (tid < BM) {
+    const int ry = tid >> 5, px = tid & 31;
+    rowoff[tid] = (((long long)n * g.DH + (y0 + ry)) * g.DW + (x0 + px)) * g.dst_cstride;
+  }
+  if (tid < 9) {
+    s_ho[tid] = (g.offy[tid] * HWD + g.offx[tid]) * X3_ROWB;
+    s_wc[tid] = g.wofs[tid] >> 4;                                 // first K chunk of the tap
+  }
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const int wchunks = g.wstride >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n * img_elems, img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wfrag), 2ll * wchunks * J * 3 * 1024);
+
+  int h_off[NH];
+  float lim[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int hrow = (tid + 256 * j) >> 2;
+    const int hy = hrow / HWD, hx = hrow - hy * HWD;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+    h_off[j] = ok ? (iy * g.SW + ix) * g.src_cstride + lcol4 * 4 : -1;
+    lim[j] = ok ? __builtin_inff() : 0.f;
+  }
+  __syncthreads();
+
+  const int kch = g.K >> 4;
+  const int nch = 9 * kch;
+  const int jt0 = (co0 >> 5) + wn * TN;                            // first 32-row weight tile of this wave
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  float4 rh[NH];
+  auto load_halo = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < NH; ++j) rh[j] = bld4(rsA, h_off[j] >= 0 ? (unsigned)(h_off[j] + kc * 16) * 4u : OOB);
+  };
+  auto store_halo = [&](int kc) {
+    float4 p_sc = zero4(), p_sh = zero4();
+    if (has_pro) { p_sc = ld4(&s_pro[kc * 16 + lcol4 * 4]); p_sh = ld4(&s_pro[DCS_PRO_MAXK + kc * 16 + lcol4 * 4]); }
+#pragma unroll
+    for (int j = 0; j < NH; ++j) {
+      const int hrow = (tid + 256 * j) >> 2;
+      if (NH * 64 != HROWS && hrow >= HROWS) continue;
+      float4 v = rh[j];
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[j]);
+      uint2 p1, p2, p3;
+      split3_quad(v, p1, p2, p3);
+      unsigned char* q = sm + hrow * X3_ROWB + lcol4 * 8;
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + 32) = p2;
+      *reinterpret_cast<uint2*>(q + 64) = p3;
+    }
+  };
+  bf16x8 fb[2][TN][3];
+  int lw_kc = 0, lw_t = 0;            // the next weight chunk to load
+  auto load_w = [&](auto S) {         // chunk parity S: odd chunks come from the sign-flipped copy
+    constexpr int s_ = decltype(S)::value;
+    const int c = s_wc[lw_t] + lw_kc;
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned off = (unsigned)(((c * J + jt0 + b) * 3 + p) * 1024) + lane16 + (s_ ? neg_off : 0u);
+        fb[s_][b][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+      }
+    if (lw_kc * 9 + lw_t + 1 < nch) { lw_t += 1; if (lw_t == 9) { lw_t = 0; lw_kc += 1; } }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  f32x16 acc[2][TM][TN];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s_][a][b][r] = 0.f;
+
+  load_halo(0);
+  load_w(P0{});                          // chunk 0
+  store_halo(0);
+  if (kch > 1) load_halo(1);
+  __syncthreads();
+
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+  bf16x8 fa[TM][3];
+  const unsigned char* Abase = sm + ((wm * 2 + 1) * HWD + l31 + 1) * X3_ROWB + h * 16;
+  int kc = 0, t = 0;
+  auto step = [&](auto PAR) {
+    constexpr int par = decltype(PAR)::value;
+    const unsigned char* Ab = Abase + s_ho[t];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+      const int pa = o == 0 ? 0 : (o == 1 ? 2 : 1);
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a][pa] = *reinterpret_cast<const bf16x8*>(Ab + a * HWD * X3_ROWB + pa * 32);
+    }
+    load_w(std::integral_constant<int, 1 - par>{});                 // the next chunk's weight fragments
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[par][a][b] =
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[par][b][PB[term]], acc[par][a][b], 0, 0, 0);
+    t += 1;
+    if (t == 9) {
+      t = 0; kc += 1;
+      if (kc < kch) {
+        __syncthreads();
+        store_halo(kc);
+        if (kc + 1 < kch) load_halo(kc + 1);
+        __syncthreads();
+      }
+    }
+  };
+  for (int i = 0; i < nch; i += 2) {
+    step(P0{});
+    if (i + 1 < nch) step(P1{});
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][a][b][r] -= acc[1][a][b][r];
+  __syncthreads();                         // the halo is dead: the epilogue reuses its LDS
+
+  conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
+                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb);
+}
+
+// w [rows][wstride] fp32 -> fragment-major split image (see conv3x3_x3w_kernel): unit (((c*J + j)*3 + p)*2 + h)*32 + r
+// (16 bytes) = piece p of row 32j + r, channels 16c + 8h .. +7; rows beyond `rows` are zero; a sign-flipped copy follows.
+__global__ void split_weight_frag_kernel(const float* __restrict__ w, u32x4* __restrict__ out, const int rows,
+                                         const int wstride, const int J, const long long units) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (c, j, h, r): one thread writes 3 pieces
+  const long long nthreads = (long long)(wstride >> 4) * J * 64;
+  if (u >= nthreads) return;
+  const int r = (int)(u & 31), hh = (int)((u >> 5) & 1);
+  const long long cj = u >> 6;
+  const int j = (int)(cj % J);
+  const long long c = cj / J;
+  const int row = 32 * j + r;
+  u32x4 q1 = {0, 0, 0, 0}, q2 = q1, q3 = q1;
+  if (row < rows) {
+    const float* src = w + (long long)row * wstride + c * 16 + hh * 8;
+    const float4 v0 = ld4(src), v1 = ld4(src + 4);
+    unsigned a1, a2, a3;
+    split3_pair(v0.x, v0.y, a1, a2, a3); q1.x = a1; q2.x = a2; q3.x = a3;
+    split3_pair(v0.z, v0.w, a1, a2, a3); q1.y = a1; q2.y = a2; q3.y = a3;
+    split3_pair(v1.x, v1.y, a1, a2, a3); q1.z = a1; q2.z = a2; q3.z = a3;
+    split3_pair(v1.z, v1.w, a1, a2, a3); q1.w = a1; q2.w = a2; q3.w = a3;
+  }
+  const long long base = ((cj * 3) * 2 + hh) * 32 + r;
+  const u32x4 f = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+  out[base] = q1; out[base + 64] = q2; out[base + 128] = q3;
+  out[units + base] = q1 ^ f; out[units + base + 64] = q2 ^ f; out[units + base + 128] = q3 ^ f;
+}
+
 // geometries conv3x3_x3_kernel covers: the nine taps of a dense 3x3 / stride 1 / pad 1 window in any order
 bool conv3x3_halo_eligible(const DcsConvGeom* g, int th) {
   if (g->stem || g->ntaps != 9 || g->sy != 1 || g->sx != 1 || g->dsy != 1 || g->dsx != 1 || g->dy0 || g->dx0) return false;
@@ -1170,5 +1377,49 @@ extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab,
     hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT, pro);
   else
     hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT, pro);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_split_weight_frag(const float* w, void* out, int64_t rows, int wstride, void* stream) {
+  DCS_CHECK_ARG(w && out && rows > 0 && wstride > 0 && (wstride & 15) == 0 && dcs_aligned16(w) && dcs_aligned16(out));
+  const int J = (int)((rows + 31) / 32);
+  const long long units = (long long)(wstride >> 4) * J * 3 * 64;
+  const long long nthreads = (long long)(wstride >> 4) * J * 64;
+  DCS_CHECK_ARG(units * 32 < 0x7FFFFFFFll);
+  hipLaunchKernelGGL(split_weight_frag_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, dcs_stream(stream), w,
+                     reinterpret_cast<u32x4*>(out), (int)rows, wstride, J, units);
+  DCS_LAUNCH_RET();
+}
+
+// dcs_conv_gather_x3 for dense 3x3 / stride 1 geometries with the weights in dcs_split_weight_frag layout
+extern "C" int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, float* dst, const DcsConvGeom* geom,
+                               int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
+                               const float* bn, int relu, void* stream) {
+  int rc = check_geom(geom);
+  if (rc != DCS_OK) return rc;
+  DCS_CHECK_ARG(src && wfrag && dst && dcs_aligned16(src) && dcs_aligned16(wfrag) && geom->dst_cstride >= geom->Cout);
+  const int bn_ = geom->Cout > 64 ? 128 : 64;
+  const int th = bn_ == 64 ? 8 : 4;
+  if (geom->Cout <= 32 || (geom->wstride & 15) || !conv3x3_halo_eligible(geom, th)) return DCS_E_UNSUPPORTED;
+  for (int t = 0; t < 9; ++t)
+    if (geom->wofs[t] & 15) return DCS_E_UNSUPPORTED;
+  if ((long long)geom->SH * geom->SW * geom->src_cstride * 4 > 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
+  const BnBwdEpi bnb{bn_y, bn_mask, bn, relu};
+  DCS_CHECK_ARG(!(stats && accumulate && !bnb.y));
+  DCS_CHECK_ARG(!pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(pro)));
+  DCS_CHECK_ARG(!bnb.y || (stats && bnb.bn && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout && dcs_aligned16(dst) &&
+                           dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
+  const long long M = (long long)geom->N * geom->TY * geom->TX;
+  const int ntiles = (geom->Cout + bn_ - 1) / bn_;
+  const int J = (geom->Cout + 31) / 32;
+  const long long units = (long long)(geom->wstride >> 4) * J * 3 * 64;
+  hipStream_t s = dcs_stream(stream);
+  const unsigned char* wf = reinterpret_cast<const unsigned char*>(wfrag);
+  if (bn_ == 64)
+    hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8>), dim3((unsigned)((M / 256) * ntiles)), dim3(256), 0, s, src, wf, bias, dst,
+                       *geom, accumulate, ntiles, stats, bnb, pro, J, (unsigned)(units * 16));
+  else
+    hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4>), dim3((unsigned)((M / 128) * ntiles)), dim3(256), 0, s, src, wf, bias, dst,
+                       *geom, accumulate, ntiles, stats, bnb, pro, J, (unsigned)(units * 16));
   DCS_LAUNCH_RET();
 }

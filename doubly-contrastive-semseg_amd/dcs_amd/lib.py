@@ -36,6 +36,8 @@ SIGNATURES = {
     "dcs_conv_wgrad": [_P, _P, _P, _G, _I, _I, _I, _P],
     "dcs_split_weight": [_P, _P, _L, _I, _P],
     "dcs_conv_gather_x3": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P],
+    "dcs_split_weight_frag": [_P, _P, _L, _I, _P],
+    "dcs_conv3x3_x3w": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _P],
     "dcs_conv_wgrad_x3": [_P, _P, _P, _G, _I, _I, _I, _P, _P],
     "dcs_conv_gather_pro": [_P, _P, _P, _P, _G, _I, _P, _P, _I, _L, _P],
     "dcs_conv_wgrad_pro": [_P, _P, _P, _G, _I, _I, _I, _P, _P],

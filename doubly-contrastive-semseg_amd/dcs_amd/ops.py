@@ -235,10 +235,47 @@ def split_weight(wk):
     return out
 
 
+def split_weight_frag(wk):
+    """[rows, ...] fp32 -> the fragment-major split image (+ sign-flipped copy) dcs_conv3x3_x3w reads straight into its MFMA
+    operands; cached per step like split_weight."""
+    key = ("frag", wk.data_ptr(), tuple(wk.shape), tuple(wk.stride()))
+    hit = _split_cache.get(key)
+    if hit is not None:
+        return hit[1]
+    rows = wk.shape[0]
+    ws = wk.numel() // rows
+    J = -(-rows // 32)
+    out = torch.empty((2 * (ws // 16) * J * 3 * 256,), device=wk.device, dtype=_F32)
+    _call("dcs_split_weight_frag", _p(wk), _p(out), rows, ws, _stream())
+    if len(_split_cache) >= 1024:
+        _split_cache.clear()
+    _split_cache[key] = (wk, out)
+    return out
+
+
+def x3w_ok(g):
+    """Dense 3x3 / stride 1 launches wide enough for 128-channel tiles and with enough tiles to fill the chip run the
+    halo-resident kernel that takes its weight fragments straight from global memory (csrc/conv_split.hip,
+    conv3x3_x3w_kernel: +5..11 % over the LDS-staged weights on 128..512 channels, bitwise the same results)."""
+    ok = getattr(g, "_x3w", None)
+    if ok is None:
+        offs = {(g.offy[t], g.offx[t]) for t in range(g.ntaps)}
+        ok = (not g.stem and g.ntaps == 9 and g.sy == 1 and g.dsy == 1 and g.dy0 == 0 and g.dx0 == 0 and g.Cout > 64 and
+              g.K % 32 == 0 and g.wstride % 16 == 0 and g.TX % 32 == 0 and g.TY % 4 == 0 and g.SH == g.TY and
+              g.SW == g.TX and g.DH == g.TY and g.DW == g.TX and all(g.wofs[t] % 16 == 0 for t in range(g.ntaps)) and
+              offs == {(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)} and
+              (g.N * g.TY * g.TX // 128) * (-(-g.Cout // 128)) >= 1024 and g.SH * g.SW * g.src_cstride * 4 < 2 ** 31)
+        g._x3w = ok
+    return ok and os.environ.get("DCS_X3W", "1") != "0" and os.environ.get("DCS_X3_HALO", "1") == "1"
+
+
 def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None, ns=1, slab_n=0):
     """One launch of the gather kernel family.  bnb = (y, mask, bn record, relu) or None."""
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
-    if x3_ok(g):
+    if ns == 1 and x3_ok(g) and x3w_ok(g):
+        _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats),
+              _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _stream())
+    elif x3_ok(g):
         _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats),
               _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _stream())
     elif bnb is not None:

@@ -117,6 +117,16 @@ int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, 
                        int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
                        const float* bn, int relu, int nsplit, int64_t slab_stride, void* stream);
 
+/* Dense 3x3 / stride 1 / pad 1 geometries (TX % 32 == 0, TY % 8 (Cout <= 64) or % 4 == 0, K % 32 == 0), weights straight
+ * from global memory into the MFMA fragments: dcs_split_weight_frag lays them out fragment-major (unit
+ * (((c*J + j)*3 + p)*2 + h)*32 + r of 16 bytes = piece p of row 32j + r, channels 16c + 8h .. +7, J = ceil(rows / 32)),
+ * followed by a sign-flipped copy (2 x wstride/16 x J x 3 KiB in all); dcs_conv3x3_x3w is dcs_conv_gather_x3 (one K
+ * split) on that layout.  Other geometries: DCS_E_UNSUPPORTED. */
+int dcs_split_weight_frag(const float* w, void* out, int64_t rows, int wstride, void* stream);
+int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, float* dst, const DcsConvGeom* geom,
+                    int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
+                    const float* bn, int relu, void* stream);
+
 /* dcs_conv_wgrad / dcs_conv_wgrad_pro (pro nullable) on the bf16 matrix cores, operands as three bf16 pieces; slabs of
  * odd split index carry the hardware's rounding bias with the opposite sign, so an EVEN nsplit cancels it in
  * dcs_reduce_slab.  Cout % 4 == 0; the stem in its seven-tap form with TX % 16 == 0, Cout 64, wstride 224, no prologue

@@ -756,3 +756,40 @@ def test_split_bf16_convolution_with_resident_halo(ops, monkeypatch, N, H, W, Ci
     assert float(ea.abs().max()) / scale <= 1.5 * float(eb.abs().max()) / scale + 1e-7
     assert abs(float(ea.sum() / ea.abs().sum())) < 0.03
     close(sa, sb, 2e-5, "batch statistics"); close(da, db, 2e-5, "data gradient"); close(qa, qb, 2e-5, "BatchNorm-backward sums")
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(4, 16, 64, 128, 128), (2, 8, 32, 256, 128), (1, 12, 96, 128, 256), (2, 16, 64, 64, 64)])
+def test_halo_kernel_with_weight_fragments_from_global_memory(ops, monkeypatch, N, H, W, Cin, Cout):
+    """dcs_conv3x3_x3w (weight fragments straight from global memory in dcs_split_weight_frag layout, no per-tap barrier)
+    performs exactly the arithmetic of conv3x3_x3_kernel: outputs, batch statistics, prologue and the data gradient with
+    BatchNorm-backward sums must be BITWISE those of the LDS-staged halo kernel (DCS_X3_HALO=2 forces it on small maps)."""
+    import ctypes as C
+    from dcs_amd.ops import _p, _call, _stream
+    monkeypatch.setenv("DCS_KSPLIT", "0")
+    monkeypatch.setenv("DCS_X3_HALO", "2")
+    x = rnd(N, H, W, Cin, seed=131).to(DEV)
+    w = cl(rnd(Cout, Cin, 3, 3, seed=132, scale=0.05).to(DEV))
+    gam, bet = (rnd(Cin, seed=133) * 0.1 + 1).to(DEV), (rnd(Cin, seed=134) * 0.1).to(DEV)
+    bn = ops.bn_finalize(ops.colsum(x.reshape(-1, Cin), moments=True), gam, bet, torch.zeros(Cin, device=DEV),
+                         torch.ones(Cin, device=DEV), N * H * W, True)
+    g = ops.geom_fwd(N, H, W, Cin, Cout, 3, 3, 1, 1)
+    ref, st = ops.conv_fwd(x, w, 1, 1, want_stats=True, pro=bn)
+    y = torch.empty_like(ref)
+    part, G, G1 = ops._stats_buffer(N * H * W, Cout, x.device)
+    _call("dcs_conv3x3_x3w", _p(x), _p(ops.split_weight_frag(ops.krsc(w))), None, _p(y), C.byref(g), 0, _p(part), _p(bn), None, None,
+          None, 0, _stream())
+    assert torch.equal(y, ref) and torch.equal(ops._stats_reduce(part, G, G1, Cout, N * H * W), st)
+    # data gradient accumulating into a tensor, with the BatchNorm-backward sums
+    dy = rnd(N, H, W, Cout, seed=135).to(DEV)
+    base = rnd(N, H, W, Cin, seed=136).to(DEV)
+    wp = ops.pack_dgrad_weight(w)
+    d_ref, s_ref = ops.conv_dgrad(dy, wp, (H, W), 1, 1, out=base.clone(), accumulate=True, bnb=(x, None, bn, True))
+    gd = ops.geoms_dgrad(N, H, W, Cin, Cout, 3, 3, 1, 1)[0]
+    d = base.clone()
+    tiles = -(-(N * H * W) // 128)
+    partd = torch.empty((tiles, 2, Cin), device=DEV)
+    _call("dcs_conv3x3_x3w", _p(dy), _p(ops.split_weight_frag(wp)), None, _p(d), C.byref(gd), 1, _p(partd), None, _p(x), None, _p(bn),
+          1, _stream())
+    sums = torch.empty((2, Cin), device=DEV)
+    _call("dcs_colsum_final", _p(partd), _p(sums), 1, tiles, Cin, 1.0, 0.0, _stream())
+    assert torch.equal(d, d_ref) and torch.equal(sums, s_ref)

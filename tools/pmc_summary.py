@@ -11,7 +11,7 @@ import json
 import sys
 from collections import defaultdict
 
-GROUPS = {"conv_gather": ("conv_gather_kernel", "conv_gather_x3_kernel", "conv3x3_x3_kernel"), "conv_wgrad": ("conv_wgrad", "stem_wgrad_kernel")}
+GROUPS = {"conv_gather": ("conv_gather_kernel", "conv_gather_x3_kernel", "conv3x3_x3_kernel", "conv3x3_x3w_kernel"), "conv_wgrad": ("conv_wgrad", "stem_wgrad_kernel")}
 
 
 def group_of(name):
