@@ -646,6 +646,204 @@ void conv_wgrad3x3_x3_kernel(const float* __restrict__ src, const float* __restr
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv_wgrad3x3_x3_kernel with a ROLLING input window.  Timing experiments on that kernel (loop parts switched off, results
+// discarded) put 35 % of its time into staging (global load, split, LDS write of dy[16][64] and the 3 x 18-pixel halo per
+// chunk) and the MFMA-only loop at 286-304 TFLOP/s.  Here a block walks DOWN a 16-pixel-wide column strip: two of the
+// three halo rows of the next chunk are already resident, so a chunk stages one new input row (18 pixels) and dy instead of
+// three rows -- the halo lives in a ring of four row slots (row & 3: the slot of row ty+2 is free while rows ty-1..ty+1 are
+// read).  Only the first chunk of a strip (or of a split) loads three rows, behind two barriers.  Work units are
+// (image, strip, row) in that order; a split is a range of units.
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                              const DcsConvGeom g, const int dy_cstride, const int split0, const int cps, const int ciT,
+                              const float* __restrict__ pro) {
+  constexpr int CHP = 16, HWP = CHP + 2;
+  constexpr int PIECE = 128, ROW = 3 * PIECE + 64;             // 448 = 192 (mod 256)
+  constexpr int NSX = (3 * HWP * 16 + 255) / 256;              // 4 register slots hold up to three halo rows
+  constexpr int NSLOT = 1 + NSX;
+  constexpr int DB = CHP * ROW, XB = 4 * HWP * ROW;            // dy double buffer, ring of four halo rows
+  __shared__ __attribute__((aligned(16))) unsigned char sm[2 * DB + XB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lcol4 = tid & 15, lrow = tid >> 4;
+
+  const int ciTile = blockIdx.x % ciT, coTile = blockIdx.x / ciT;
+  const int co0 = coTile * 64, ci0 = ciTile * 64;
+  const int split = blockIdx.y;
+  const bool odd = ((split0 + split) & 1) != 0;
+  const int cpr = g.TX / CHP;                           // strips per image
+  const int nunits_total = g.N * cpr * g.TY;
+  const int ubeg = split * cps;
+  const int uend = ubeg + cps < nunits_total ? ubeg + cps : nunits_total;
+  const int nch = uend > ubeg ? uend - ubeg : 0;
+
+  // the NEXT unit to be loaded (uniform), advanced incrementally
+  int q_n, q_tx, q_ty;
+  {
+    const int u = ubeg < nunits_total ? ubeg : 0;
+    const int strip = u / g.TY;
+    q_ty = u - strip * g.TY;
+    q_n = strip / cpr;
+    q_tx = (strip - q_n * cpr) * CHP;
+  }
+  const int n0 = q_n;
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const long long dimg_elems = (long long)g.TY * g.TX * dy_cstride;
+  const __amdgpu_buffer_rsrc_t rsX = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsD = make_rsrc(dy + (long long)n0 * dimg_elems, ((long long)g.N - n0) * dimg_elems * 4);
+  const int kc = ci0 + lcol4 * 4, cc = co0 + lcol4 * 4;
+  const bool kok = kc < g.K, ccok = cc < g.Cout;
+  const bool has_pro = pro != nullptr;
+  float4 p_sc = zero4(), p_sh = zero4();
+  if (has_pro && kok) { p_sc = ld4(pro + kc); p_sh = ld4(pro + g.K + kc); }
+
+  // halo register slots: element e = tid + 256 k -> (row in the list rr, pixel hx)
+  int xs_rr[NSX], xs_hx[NSX];
+#pragma unroll
+  for (int k = 0; k < NSX; ++k) {
+    const int hrow = (tid + 256 * k) >> 4;
+    xs_rr[k] = hrow / HWP;
+    xs_hx[k] = hrow - xs_rr[k] * HWP;
+  }
+
+  float4 rs[NSLOT];
+  float lim[NSX];
+  int xs_slot[NSX];                   // ring slot the held row goes to, or -1
+  int l_unit = 0;                     // index (relative to ubeg) of the unit being loaded
+  bool l_cold = true;                 // ... and whether it needs all three rows
+  bool held_cold = true;              // the same for the unit the registers hold
+  auto load_slot = [&](int sl) {
+    if (sl == 0) {
+      const int off = (((q_n - n0) * g.TY + q_ty) * g.TX + q_tx + lrow) * dy_cstride + cc;
+      rs[0] = bld4(rsD, (ccok && l_unit < nch) ? (unsigned)off * 4u : OOB);
+    } else {
+      const int k = sl - 1;
+      const int nrows = l_cold ? 3 : 1;
+      const bool valid = xs_rr[k] < nrows;
+      const int iy = l_cold ? q_ty - 1 + xs_rr[k] : q_ty + 1;
+      const int ix = q_tx - 1 + xs_hx[k];
+      const bool ok = valid && kok && l_unit < nch && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+      const int off = (((q_n - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
+      rs[sl] = bld4(rsX, ok ? (unsigned)off * 4u : OOB);
+      if (has_pro) lim[k] = ok ? __builtin_inff() : 0.f;
+      xs_slot[k] = valid ? ((iy + 4) & 3) : -1;
+    }
+  };
+  auto advance_unit = [&]() {         // after all slots of a unit were loaded
+    held_cold = l_cold;
+    l_unit += 1;
+    q_ty += 1;
+    l_cold = false;
+    if (q_ty >= g.TY) {
+      q_ty = 0; l_cold = true;
+      q_tx += CHP;
+      if (q_tx >= g.TX) { q_tx = 0; q_n += 1; }
+    }
+  };
+  auto store_slot = [&](int sl, int buf) {
+    float4 v = rs[sl];
+    unsigned char* q;
+    if (sl == 0) {
+      if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
+      q = sm + buf * DB + lrow * ROW + lcol4 * 8;
+    } else {
+      const int k = sl - 1;
+      if (xs_slot[k] < 0) return;
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[k]);
+      q = sm + 2 * DB + (xs_slot[k] * HWP + xs_hx[k]) * ROW + lcol4 * 8;
+    }
+    uint2 p1, p2, p3;
+    split3_quad(v, p1, p2, p3);
+    *reinterpret_cast<uint2*>(q) = p1;
+    *reinterpret_cast<uint2*>(q + PIECE) = p2;
+    *reinterpret_cast<uint2*>(q + 2 * PIECE) = p3;
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  int c_ty = q_ty;                    // row of the unit being computed
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  advance_unit();
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, 0);
+#pragma unroll
+  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+  advance_unit();
+  __syncthreads();
+
+  const int tj = lane & 15;
+  const int tr_off = (8 * h + (tj >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (tj & 3)) * 2;
+  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+  auto frag = [&](const unsigned char* base) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
+    const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    return __builtin_bit_cast(bf16x8, v);
+  };
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    const bool warm = !held_cold;       // may the next unit's data go to LDS while this one is computed?
+    const unsigned char* Db = sm + buf * DB + tr_off + (wm * 32) * 2;
+    const unsigned char* Xb = sm + 2 * DB + tr_off + (wn * 32) * 2;
+    bf16x8 fa[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) fa[p] = frag(Db + p * PIECE);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int r = t / 3, sx = t % 3;
+      const int slot = (c_ty + r + 3) & 3;                              // ring slot of input row c_ty - 1 + r
+      bf16x8 fb[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) fb[p] = frag(Xb + (slot * HWP + sx) * ROW + p * PIECE);
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[term]], fb[PB[term]], acc[t], 0, 0, 0);
+      // stage the next unit (dy + one new row = slots 0..2: 18 pixels x 16 quads fill slot 1 and 32 lanes of slot 2) and
+      // refill those registers with the unit after; slots 3, 4 only ever hold rows of a strip start
+      if (t < 3 && warm) {
+        store_slot(t, buf ^ 1);
+        load_slot(t);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    c_ty += 1;
+    if (c_ty >= g.TY) c_ty = 0;
+    if (!warm) {                        // next unit starts a strip: its three rows overwrite slots this unit still read
+      __syncthreads();
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, buf ^ 1);
+#pragma unroll
+      for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
+    } else if (l_cold) {                // the unit after next starts a strip: its rows 2 and 3 need slots 3, 4 as well
+      load_slot(3);
+      load_slot(4);
+    }
+    advance_unit();
+    __syncthreads();
+  }
+
+  float* out = slab + (long long)(split0 + split) * g.Cout * g.wstride;
+  const int ci = ci0 + wn * 32 + l31;
+  if (ci < g.K) {
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (co < g.Cout) out[(long long)co * g.wstride + t * g.K + ci] = odd ? -acc[t][r] : acc[t][r];
+      }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight gradient of the 7x7 / stride 2 / pad 3 stem on the bf16 matrix cores (split-bf16 counterpart of
 // stem_wgrad_kernel): all seven filter rows per block, a chunk = 16 consecutive output pixels of one output row.  dy is
 // staged as [pixel][piece][64 channels]; the 7 x 38-pixel input patch as one contiguous bf16 run per (filter row, piece).
@@ -1364,6 +1562,20 @@ extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab,
     const int cps = (int)((nchunks + nsplit - 1) / nsplit);
     const int coT = (geom->Cout + 63) / 64, ciT = (geom->K + 63) / 64;
     const long long span = ((long long)cps * 16 + 4ll * geom->SW) * geom->src_cstride * 4;
+    {
+      // rolling-window kernel: units are (image, strip, row); a split may reach into the following image(s)
+      const long long per_img = (long long)geom->TY * (geom->TX / 16);
+      long long imgs = cps / per_img + 2;
+      if (imgs > geom->N) imgs = geom->N;
+      const long long xbytes = imgs * geom->SH * geom->SW * geom->src_cstride * 4;
+      const long long dbytes = imgs * geom->TY * geom->TX * dy_cstride * 4;
+      const char* roll = getenv("DCS_WGRAD_ROLL");
+      if ((roll == nullptr || roll[0] != '0') && xbytes < 0x7FFFFFFFll && dbytes < 0x7FFFFFFFll) {
+        hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0, s, src, dy,
+                           slab, *geom, dy_cstride, split0, cps, ciT, pro);
+        DCS_LAUNCH_RET();
+      }
+    }
     if ((long long)cps * 16 * dy_cstride * 4 < 0x7FFFFFFFll && span < 0x7FFFFFFFll) {
       hipLaunchKernelGGL(conv_wgrad3x3_x3_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0, s, src, dy,
                          slab, *geom, dy_cstride, split0, cps, ciT, pro);
