@@ -254,8 +254,8 @@ def split_weight_frag(wk):
 
 
 def x3w_ok(g):
-    """Dense 3x3 / stride 1 launches wide enough for 128-channel tiles and with enough tiles to fill the chip run the
-    halo-resident kernel that takes its weight fragments straight from global memory (csrc/conv_split.hip,
+    """Dense 3x3 / stride 1 launches wide enough for 128-channel tiles and with at least 256 tiles (measured: 16x32 maps of
+    512 channels 169 -> 196 TF, 32x64 of 128 channels 147 -> 168 TF against the per-tap kernel) run the halo-resident kernel that takes its weight fragments straight from global memory (csrc/conv_split.hip,
     conv3x3_x3w_kernel: +5..11 % over the LDS-staged weights on 128..512 channels, bitwise the same results)."""
     ok = getattr(g, "_x3w", None)
     if ok is None:
@@ -264,7 +264,8 @@ def x3w_ok(g):
               g.K % 32 == 0 and g.wstride % 16 == 0 and g.TX % 32 == 0 and g.TY % 4 == 0 and g.SH == g.TY and
               g.SW == g.TX and g.DH == g.TY and g.DW == g.TX and all(g.wofs[t] % 16 == 0 for t in range(g.ntaps)) and
               offs == {(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)} and
-              (g.N * g.TY * g.TX // 128) * (-(-g.Cout // 128)) >= 1024 and g.SH * g.SW * g.src_cstride * 4 < 2 ** 31)
+              (g.N * g.TY * g.TX // 128) * (-(-g.Cout // 128)) >= int(os.environ.get("DCS_X3W_MIN", "256")) and
+              g.SH * g.SW * g.src_cstride * 4 < 2 ** 31)
         g._x3w = ok
     return ok and os.environ.get("DCS_X3W", "1") != "0" and os.environ.get("DCS_X3_HALO", "1") == "1"
 
