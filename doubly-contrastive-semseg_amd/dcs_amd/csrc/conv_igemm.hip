@@ -238,7 +238,7 @@ void conv_gather_kernel(const float* __restrict__ src, const float* __restrict__
   }
 
   conv_epilogue<BM, BN, TM, TN, WM, 2 * (BM + BN) * LDKT>(acc, smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0,
-                                                          accumulate, stats, mtile, M, wm, wn, bnb);
+                                                          accumulate, stats, mtile, M, wm, wn, bnb, m0 + BM <= M);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -58,7 +58,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
                                               const int dst_cstride, const int Cout, const int co0, const int accumulate,
                                               float* __restrict__ stats, const long long mtile,
                                               const unsigned long long M, const int wm, const int wn,
-                                              const BnBwdEpi bnb = BnBwdEpi{nullptr, nullptr, nullptr, 0}) {
+                                              const BnBwdEpi bnb = BnBwdEpi{nullptr, nullptr, nullptr, 0},
+                                              const bool all_rows_valid = false) {
   constexpr int EPC = TN * 32;            // columns of a wave's sub-tile
   constexpr int EPL = EPC + 4;            // staging row stride (16-B aligned rows, conflict-free column writes)
   constexpr int EPV = EPC / 4;            // float4 per staged row
@@ -93,7 +94,8 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
         const int rl = (r & 3) + 8 * (r >> 2) + 4 * h;
         const float v = acc[a][b][r] + bvv;
         stg[rl * EPL + b * 32 + l31] = v;
-        if (stats && !do_bnb && rowoff[row0 + rl] >= 0) { ssum[b] += v; ssq[b] = fmaf(v, v, ssq[b]); }
+        // all_rows_valid (block-uniform: the tile lies inside the tensor) skips 16 LDS look-ups per 32 x 32 sub-tile
+        if (stats && !do_bnb && (all_rows_valid || rowoff[row0 + rl] >= 0)) { ssum[b] += v; ssq[b] = fmaf(v, v, ssq[b]); }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

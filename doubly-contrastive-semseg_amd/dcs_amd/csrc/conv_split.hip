@@ -289,7 +289,7 @@ void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* _
       for (int r = 0; r < 16; ++r) acc[0][a][b][r] -= acc[1][a][b][r];
 
   conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
-                                                 mtile, M, wm, wn, bnb);
+                                                 mtile, M, wm, wn, bnb, m0 + BM <= M);
 }
 
 
@@ -1218,7 +1218,7 @@ void conv3x3_x3_kernel(const float* __restrict__ src, const unsigned char* __res
       for (int r = 0; r < 16; ++r) acc[0][a][b][r] -= acc[1][a][b][r];
 
   conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
-                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb);
+                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1397,7 +1397,7 @@ void conv3x3_x3w_kernel(const float* __restrict__ src, const unsigned char* __re
   __syncthreads();                         // the halo is dead: the epilogue reuses its LDS
 
   conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
-                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb);
+                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb, true);
 }
 
 // w [rows][wstride] fp32 -> fragment-major split image (see conv3x3_x3w_kernel): unit (((c*J + j)*3 + p)*2 + h)*32 + r
