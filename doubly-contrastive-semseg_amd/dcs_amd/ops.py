@@ -254,17 +254,19 @@ def split_weight_frag(wk):
 
 
 def x3w_ok(g):
-    """Dense 3x3 / stride 1 launches wide enough for 128-channel tiles and with at least 256 tiles (measured: 16x32 maps of
-    512 channels 169 -> 196 TF, 32x64 of 128 channels 147 -> 168 TF against the per-tap kernel) run the halo-resident kernel that takes its weight fragments straight from global memory (csrc/conv_split.hip,
-    conv3x3_x3w_kernel: +5..11 % over the LDS-staged weights on 128..512 channels, bitwise the same results)."""
+    """Dense 3x3 / stride 1 launches (8 x 32-pixel tiles of <= 64 channels, 4 x 32 of 128) with at least 256 tiles run
+    the halo-resident kernel that takes its weight fragments straight from global memory (csrc/conv_split.hip,
+    conv3x3_x3w_kernel: bitwise the results of the LDS-staged weights, +4..13 % on 64 channels, +5..11 % on 128..512;
+    against the per-tap kernel on small maps: 16x32 of 512 channels 169 -> 196 TF, 32x64 of 128 channels 147 -> 168)."""
     ok = getattr(g, "_x3w", None)
     if ok is None:
         offs = {(g.offy[t], g.offx[t]) for t in range(g.ntaps)}
-        ok = (not g.stem and g.ntaps == 9 and g.sy == 1 and g.dsy == 1 and g.dy0 == 0 and g.dx0 == 0 and g.Cout > 64 and
-              g.K % 32 == 0 and g.wstride % 16 == 0 and g.TX % 32 == 0 and g.TY % 4 == 0 and g.SH == g.TY and
-              g.SW == g.TX and g.DH == g.TY and g.DW == g.TX and all(g.wofs[t] % 16 == 0 for t in range(g.ntaps)) and
+        ok = (not g.stem and g.ntaps == 9 and g.sy == 1 and g.dsy == 1 and g.dy0 == 0 and g.dx0 == 0 and g.Cout > 32 and
+              g.K % 32 == 0 and g.wstride % 16 == 0 and g.TX % 32 == 0 and g.TY % (8 if g.Cout <= 64 else 4) == 0 and
+              g.SH == g.TY and g.SW == g.TX and g.DH == g.TY and g.DW == g.TX and all(g.wofs[t] % 16 == 0 for t in range(g.ntaps)) and
               offs == {(a, b) for a in (-1, 0, 1) for b in (-1, 0, 1)} and
-              (g.N * g.TY * g.TX // 128) * (-(-g.Cout // 128)) >= int(os.environ.get("DCS_X3W_MIN", "256")) and
+              (g.N * g.TY * g.TX // (256 if g.Cout <= 64 else 128)) * (-(-g.Cout // 128)) >=
+              int(os.environ.get("DCS_X3W_MIN", "256")) and
               g.SH * g.SW * g.src_cstride * 4 < 2 ** 31)
         g._x3w = ok
     return ok and os.environ.get("DCS_X3W", "1") != "0" and os.environ.get("DCS_X3_HALO", "1") == "1"
