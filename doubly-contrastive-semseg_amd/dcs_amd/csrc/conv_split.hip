@@ -656,7 +656,7 @@ void conv_wgrad3x3_x3_kernel(const float* __restrict__ src, const float* __restr
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                               const DcsConvGeom g, const int dy_cstride, const int split0, const int cps, const int ciT,
-                              const float* __restrict__ pro) {
+                              const float* __restrict__ pro, const int dbg) {
   constexpr int CHP = 16, HWP = CHP + 2;
   constexpr int PIECE = 128, ROW = 3 * PIECE + 64;             // 448 = 192 (mod 256)
   constexpr int NSX = (3 * HWP * 16 + 255) / 256;              // 4 register slots hold up to three halo rows
@@ -794,21 +794,27 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
     const unsigned char* Db = sm + buf * DB + tr_off + (wm * 32) * 2;
     const unsigned char* Xb = sm + 2 * DB + tr_off + (wn * 32) * 2;
     bf16x8 fa[3];
+    if (!(dbg & 1) || ch == 0)
 #pragma unroll
     for (int p = 0; p < 3; ++p) fa[p] = frag(Db + p * PIECE);
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    // the input fragments of tap t + 1 are read while tap t multiplies (software pipeline over the unrolled taps)
+    auto load_fb = [&](int t, bf16x8 (&fb)[3]) {
       const int r = t / 3, sx = t % 3;
       const int slot = (c_ty + r + 3) & 3;                              // ring slot of input row c_ty - 1 + r
-      bf16x8 fb[3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) fb[p] = frag(Xb + (slot * HWP + sx) * ROW + p * PIECE);
+    };
+    bf16x8 fbq[2][3];
+    load_fb(0, fbq[0]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (t + 1 < 9) load_fb(t + 1, fbq[(t + 1) & 1]);
 #pragma unroll
       for (int term = 0; term < 6; ++term)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[term]], fb[PB[term]], acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[term]], fbq[t & 1][PB[term]], acc[t], 0, 0, 0);
       // stage the next unit (dy + one new row = slots 0..2: 18 pixels x 16 quads fill slot 1 and 32 lanes of slot 2) and
       // refill those registers with the unit after; slots 3, 4 only ever hold rows of a strip start
-      if (t < 3 && warm) {
+      if (t < 3 && warm && !(dbg & 2) && !((dbg & 8) && t == 0) && !((dbg & 16) && t > 0)) {
         store_slot(t, buf ^ 1);
         load_slot(t);
         __builtin_amdgcn_sched_barrier(0);
@@ -827,7 +833,7 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
       load_slot(4);
     }
     advance_unit();
-    __syncthreads();
+    if (!(dbg & 4)) __syncthreads();
   }
 
   float* out = slab + (long long)(split0 + split) * g.Cout * g.wstride;
@@ -1572,7 +1578,7 @@ extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab,
       const char* roll = getenv("DCS_WGRAD_ROLL");
       if ((roll == nullptr || roll[0] != '0') && xbytes < 0x7FFFFFFFll && dbytes < 0x7FFFFFFFll) {
         hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0, s, src, dy,
-                           slab, *geom, dy_cstride, split0, cps, ciT, pro);
+                           slab, *geom, dy_cstride, split0, cps, ciT, pro, getenv("DCS_X3_DBG") ? atoi(getenv("DCS_X3_DBG")) : 0);
         DCS_LAUNCH_RET();
       }
     }
