@@ -656,11 +656,10 @@ void conv_wgrad3x3_x3_kernel(const float* __restrict__ src, const float* __restr
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                               const DcsConvGeom g, const int dy_cstride, const int split0, const int cps, const int ciT,
-                              const float* __restrict__ pro, const int dbg) {
+                              const float* __restrict__ pro) {
   constexpr int CHP = 16, HWP = CHP + 2;
   constexpr int PIECE = 128, ROW = 3 * PIECE + 64;             // 448 = 192 (mod 256)
-  constexpr int NSX = (3 * HWP * 16 + 255) / 256;              // 4 register slots hold up to three halo rows
-  constexpr int NSLOT = 1 + NSX;
+  constexpr int NSX = (3 * HWP * 16 + 255) / 256;              // 256-thread passes over up to three halo rows
   constexpr int DB = CHP * ROW, XB = 4 * HWP * ROW;            // dy double buffer, ring of four halo rows
   __shared__ __attribute__((aligned(16))) unsigned char sm[2 * DB + XB];
 
@@ -678,18 +677,8 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
   const int nunits_total = g.N * cpr * g.TY;
   const int ubeg = split * cps;
   const int uend = ubeg + cps < nunits_total ? ubeg + cps : nunits_total;
-  const int nch = uend > ubeg ? uend - ubeg : 0;
 
-  // the NEXT unit to be loaded (uniform), advanced incrementally
-  int q_n, q_tx, q_ty;
-  {
-    const int u = ubeg < nunits_total ? ubeg : 0;
-    const int strip = u / g.TY;
-    q_ty = u - strip * g.TY;
-    q_n = strip / cpr;
-    q_tx = (strip - q_n * cpr) * CHP;
-  }
-  const int n0 = q_n;
+  const int n0 = (ubeg < nunits_total ? ubeg : 0) / (g.TY * cpr);      // first image this split touches
   const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
   const long long dimg_elems = (long long)g.TY * g.TX * dy_cstride;
   const __amdgpu_buffer_rsrc_t rsX = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
@@ -700,7 +689,7 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
   float4 p_sc = zero4(), p_sh = zero4();
   if (has_pro && kok) { p_sc = ld4(pro + kc); p_sh = ld4(pro + g.K + kc); }
 
-  // halo register slots: element e = tid + 256 k -> (row in the list rr, pixel hx)
+  // halo passes: element e = tid + 256 k -> (row in the list rr, pixel hx); one row = pass 0 + 32 lanes of pass 1
   int xs_rr[NSX], xs_hx[NSX];
 #pragma unroll
   for (int k = 0; k < NSX; ++k) {
@@ -709,75 +698,76 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
     xs_hx[k] = hrow - xs_rr[k] * HWP;
   }
 
-  float4 rs[NSLOT];
-  float lim[NSX];
-  int xs_slot[NSX];                   // ring slot the held row goes to, or -1
-  int l_unit = 0;                     // index (relative to ubeg) of the unit being loaded
-  bool l_cold = true;                 // ... and whether it needs all three rows
-  bool held_cold = true;              // the same for the unit the registers hold
-  auto load_slot = [&](int sl) {
-    if (sl == 0) {
-      const int off = (((q_n - n0) * g.TY + q_ty) * g.TX + q_tx + lrow) * dy_cstride + cc;
-      rs[0] = bld4(rsD, (ccok && l_unit < nch) ? (unsigned)off * 4u : OOB);
-    } else {
-      const int k = sl - 1;
-      const int nrows = l_cold ? 3 : 1;
-      const bool valid = xs_rr[k] < nrows;
-      const int iy = l_cold ? q_ty - 1 + xs_rr[k] : q_ty + 1;
-      const int ix = q_tx - 1 + xs_hx[k];
-      const bool ok = valid && kok && l_unit < nch && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
-      const int off = (((q_n - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
-      rs[sl] = bld4(rsX, ok ? (unsigned)off * 4u : OOB);
-      if (has_pro) lim[k] = ok ? __builtin_inff() : 0.f;
-      xs_slot[k] = valid ? ((iy + 4) & 3) : -1;
+  // Two register sets of three slots (dy, 16 halo pixels, 2 halo pixels): a unit's loads are issued TWO iterations before
+  // its registers are split and written to LDS (one iteration = 54 MFMAs per wave is shorter than a loaded global round
+  // trip: with one set the store waited on the loads for ~15 % of the kernel).  Every iteration issues exactly three
+  // loads -- beyond the segment they go out of range -- so that the compiler can count the loads in flight (vmcnt(3))
+  // instead of draining them all.
+  float4 rs[2][3];
+  float lim[2][2];
+  int ring[2] = {0, 0};               // ring slot the held halo row goes to
+  auto prefetch = [&](auto S, int un, int utx, int uty, bool live) {       // dy of row uty and halo row uty + 1
+    constexpr int s_ = decltype(S)::value;
+    const int off = (((un - n0) * g.TY + uty) * g.TX + utx + lrow) * dy_cstride + cc;
+    rs[s_][0] = bld4(rsD, (ccok && live) ? (unsigned)off * 4u : OOB);
+    const int iy = uty + 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int ix = utx - 1 + xs_hx[k];
+      const bool ok = xs_rr[k] == 0 && kok && live && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+      const int xoff = (((un - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
+      rs[s_][1 + k] = bld4(rsX, ok ? (unsigned)xoff * 4u : OOB);
+      if (has_pro) lim[s_][k] = ok ? __builtin_inff() : 0.f;
     }
+    ring[s_] = (iy + 4) & 3;
   };
-  auto advance_unit = [&]() {         // after all slots of a unit were loaded
-    held_cold = l_cold;
-    l_unit += 1;
-    q_ty += 1;
-    l_cold = false;
-    if (q_ty >= g.TY) {
-      q_ty = 0; l_cold = true;
-      q_tx += CHP;
-      if (q_tx >= g.TX) { q_tx = 0; q_n += 1; }
-    }
-  };
-  auto store_slot = [&](int sl, int buf) {
-    float4 v = rs[sl];
-    unsigned char* q;
-    if (sl == 0) {
-      if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-      q = sm + buf * DB + lrow * ROW + lcol4 * 8;
-    } else {
-      const int k = sl - 1;
-      if (xs_slot[k] < 0) return;
-      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[k]);
-      q = sm + 2 * DB + (xs_slot[k] * HWP + xs_hx[k]) * ROW + lcol4 * 8;
-    }
+  auto split_store = [&](float4 v, unsigned char* q) {
     uint2 p1, p2, p3;
     split3_quad(v, p1, p2, p3);
     *reinterpret_cast<uint2*>(q) = p1;
     *reinterpret_cast<uint2*>(q + PIECE) = p2;
     *reinterpret_cast<uint2*>(q + 2 * PIECE) = p3;
   };
+  auto store_slot = [&](auto S, int sl, int buf) {
+    constexpr int s_ = decltype(S)::value;
+    float4 v = rs[s_][sl];
+    if (sl == 0) {
+      if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
+      split_store(v, sm + buf * DB + lrow * ROW + lcol4 * 8);
+    } else {
+      const int k = sl - 1;
+      if (xs_rr[k] != 0) return;
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[s_][k]);
+      split_store(v, sm + 2 * DB + (ring[s_] * HWP + xs_hx[k]) * ROW + lcol4 * 8);
+    }
+  };
+  // a segment's first unit: dy and rows ty - 1, ty, ty + 1, loaded and stored here and now
+  auto cold_stage = [&](int un, int utx, int uty, int buf) {
+    {
+      const int off = (((un - n0) * g.TY + uty) * g.TX + utx + lrow) * dy_cstride + cc;
+      float4 v = bld4(rsD, ccok ? (unsigned)off * 4u : OOB);
+      if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
+      split_store(v, sm + buf * DB + lrow * ROW + lcol4 * 8);
+    }
+#pragma unroll
+    for (int k = 0; k < NSX; ++k) {
+      if (xs_rr[k] >= 3) continue;
+      const int iy = uty - 1 + xs_rr[k], ix = utx - 1 + xs_hx[k];
+      const bool ok = kok && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+      const int xoff = (((un - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
+      float4 v = bld4(rsX, ok ? (unsigned)xoff * 4u : OOB);
+      if (has_pro) v = pro_apply(v, p_sc, p_sh, ok ? __builtin_inff() : 0.f);
+      split_store(v, sm + 2 * DB + (((iy + 4) & 3) * HWP + xs_hx[k]) * ROW + lcol4 * 8);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
 
   f32x16 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-
-  int c_ty = q_ty;                    // row of the unit being computed
-#pragma unroll
-  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
-  advance_unit();
-#pragma unroll
-  for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, 0);
-#pragma unroll
-  for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
-  advance_unit();
-  __syncthreads();
 
   const int tj = lane & 15;
   const int tr_off = (8 * h + (tj >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (tj & 3)) * 2;
@@ -788,52 +778,59 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
     const s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return __builtin_bit_cast(bf16x8, v);
   };
-  for (int ch = 0; ch < nch; ++ch) {
-    const int buf = ch & 1;
-    const bool warm = !held_cold;       // may the next unit's data go to LDS while this one is computed?
-    const unsigned char* Db = sm + buf * DB + tr_off + (wm * 32) * 2;
-    const unsigned char* Xb = sm + 2 * DB + tr_off + (wn * 32) * 2;
-    bf16x8 fa[3];
-    if (!(dbg & 1) || ch == 0)
+
+  int dbuf = 0;                         // dy buffer of the unit about to be computed
+  for (int u = ubeg; u < uend;) {       // one segment = the rows of ONE column strip that fall into this split
+    const int strip = u / g.TY;
+    const int ty0 = u - strip * g.TY;
+    const int sn = strip / cpr, stx = (strip - sn * cpr) * CHP;
+    const int seg_end = (strip + 1) * g.TY < uend ? (strip + 1) * g.TY : uend;
+    const int cnt = seg_end - u;
+    __syncthreads();                    // the previous segment's readers are done with the ring and the dy buffers
+    cold_stage(sn, stx, ty0, dbuf);
+    prefetch(S1{}, sn, stx, ty0 + 1, 1 < cnt);
+    prefetch(S0{}, sn, stx, ty0 + 2, 2 < cnt);
+    __syncthreads();
+    // iteration j computes row ty0 + j from dy buffer dbuf ^ (j & 1); set P = (j + 1) & 1 holds row ty0 + j + 1 and is
+    // re-loaded with row ty0 + j + 3
+    auto step = [&](auto P, const int j) {
+      const int buf = dbuf ^ (j & 1);
+      const int c_ty = ty0 + j;
+      const bool has_next = j + 1 < cnt;
+      const unsigned char* Db = sm + buf * DB + tr_off + (wm * 32) * 2;
+      const unsigned char* Xb = sm + 2 * DB + tr_off + (wn * 32) * 2;
+      bf16x8 fa[3];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) fa[p] = frag(Db + p * PIECE);
-    // the input fragments of tap t + 1 are read while tap t multiplies (software pipeline over the unrolled taps)
-    auto load_fb = [&](int t, bf16x8 (&fb)[3]) {
-      const int r = t / 3, sx = t % 3;
-      const int slot = (c_ty + r + 3) & 3;                              // ring slot of input row c_ty - 1 + r
+      for (int p = 0; p < 3; ++p) fa[p] = frag(Db + p * PIECE);
+      // the input fragments of tap t + 1 are read while tap t multiplies (software pipeline over the unrolled taps)
+      auto load_fb = [&](int t, bf16x8 (&fb)[3]) {
+        const int r = t / 3, sx = t % 3;
+        const int slot = (c_ty + r + 3) & 3;                            // ring slot of input row c_ty - 1 + r
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fb[p] = frag(Xb + (slot * HWP + sx) * ROW + p * PIECE);
-    };
-    bf16x8 fbq[2][3];
-    load_fb(0, fbq[0]);
+        for (int p = 0; p < 3; ++p) fb[p] = frag(Xb + (slot * HWP + sx) * ROW + p * PIECE);
+      };
+      bf16x8 fbq[2][3];
+      load_fb(0, fbq[0]);
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      if (t + 1 < 9) load_fb(t + 1, fbq[(t + 1) & 1]);
+      for (int t = 0; t < 9; ++t) {
+        if (t + 1 < 9) load_fb(t + 1, fbq[(t + 1) & 1]);
 #pragma unroll
-      for (int term = 0; term < 6; ++term)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[term]], fbq[t & 1][PB[term]], acc[t], 0, 0, 0);
-      // stage the next unit (dy + one new row = slots 0..2: 18 pixels x 16 quads fill slot 1 and 32 lanes of slot 2) and
-      // refill those registers with the unit after; slots 3, 4 only ever hold rows of a strip start
-      if (t < 3 && warm && !(dbg & 2) && !((dbg & 8) && t == 0) && !((dbg & 16) && t > 0)) {
-        store_slot(t, buf ^ 1);
-        load_slot(t);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int term = 0; term < 6; ++term)
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[term]], fbq[t & 1][PB[term]], acc[t], 0, 0, 0);
+        if (t < 3) {                    // row j + 1 (loaded two iterations ago): registers -> LDS in the shadow of the MFMAs
+          if (has_next) store_slot(P, t, buf ^ 1);
+          if (t == 2) prefetch(P, sn, stx, c_ty + 3, j + 3 < cnt);       // row j + 3 into the freed set
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
-    }
-    c_ty += 1;
-    if (c_ty >= g.TY) c_ty = 0;
-    if (!warm) {                        // next unit starts a strip: its three rows overwrite slots this unit still read
       __syncthreads();
-#pragma unroll
-      for (int sl = 0; sl < NSLOT; ++sl) store_slot(sl, buf ^ 1);
-#pragma unroll
-      for (int sl = 0; sl < NSLOT; ++sl) load_slot(sl);
-    } else if (l_cold) {                // the unit after next starts a strip: its rows 2 and 3 need slots 3, 4 as well
-      load_slot(3);
-      load_slot(4);
+    };
+    for (int j = 0; j < cnt; j += 2) {
+      step(S1{}, j);
+      if (j + 1 < cnt) step(S0{}, j + 1);
     }
-    advance_unit();
-    if (!(dbg & 4)) __syncthreads();
+    dbuf ^= cnt & 1;
+    u = seg_end;
   }
 
   float* out = slab + (long long)(split0 + split) * g.Cout * g.wstride;
@@ -1578,7 +1575,7 @@ extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab,
       const char* roll = getenv("DCS_WGRAD_ROLL");
       if ((roll == nullptr || roll[0] != '0') && xbytes < 0x7FFFFFFFll && dbytes < 0x7FFFFFFFll) {
         hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0, s, src, dy,
-                           slab, *geom, dy_cstride, split0, cps, ciT, pro, getenv("DCS_X3_DBG") ? atoi(getenv("DCS_X3_DBG")) : 0);
+                           slab, *geom, dy_cstride, split0, cps, ciT, pro);
         DCS_LAUNCH_RET();
       }
     }
