@@ -21,7 +21,16 @@ from .lib import DcsConvGeom
 _F32 = torch.float32
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
+    """The current HIP stream of the current device as a raw handle.  torch.cuda.current_stream() builds a Python Stream
+    object per call (~8 us; 1100 launches per step: the small configurations are host-bound); the two C entry points
+    behind it cost ~0.5 us."""
+    if _raw_stream is not None and _raw_device is not None:
+        return C.c_void_p(_raw_stream(_raw_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -29,8 +38,14 @@ def _p(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+_fn_cache = {}
+
+
 def _call(name: str, *args):
-    rc = getattr(_lib.load(), name)(*args)
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(_lib.load(), name)
+    rc = fn(*args)
     if rc != 0:
         _lib.check(rc, name)
 
