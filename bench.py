@@ -222,9 +222,28 @@ def similarity_bench(ops, dev, ts, reps=20):
             us = ev[0].elapsed_time(ev[1]) / reps * 1e3
             res[name + "_fwd_bwd_us"] = us
             res[name + "_tflops"] = 6.0 * A * A * 128 / us / 1e6
+        if A > 1024:            # the strip kernels: time pass 1 alone = the similarity product S = X X^T + its statistics
+            os.environ["DCS_CONTRAST_DBG"] = "4"        # (the library stops after that pass; the outputs are not a loss)
+            try:
+                for _ in range(3):
+                    ops.contrast_fwd_bwd(X, y, 0, 0.07)
+                ev[0].record()
+                for _ in range(reps):
+                    ops.contrast_fwd_bwd(X, y, 0, 0.07)
+                ev[1].record()
+                torch.cuda.synchronize()
+            finally:
+                del os.environ["DCS_CONTRAST_DBG"]
+            us = ev[0].elapsed_time(ev[1]) / reps * 1e3
+            res["similarity_pass_us"] = us
+            res["similarity_pass_tflops"] = 2.0 * A * A * 128 / us / 1e6      # algorithmic 2 A^2 d of S = X X^T
+            res["similarity_pass_note"] = ("prep + strip pass 1 + combine: S = X X^T with row/column statistics; only the "
+                                           "upper-triangular 64x64 tiles are computed (executed FLOPs = half)")
         out[tag] = res
     gl = out["global"]
     out["similarity_kernel_frac_global"] = gl["loss_tflops"] / PEAK_FP32_MFMA_TFLOPS     # whole fused loss at the C4 size
+    if "similarity_pass_tflops" in gl:
+        out["similarity_pass_frac_global"] = gl["similarity_pass_tflops"] / PEAK_FP32_MFMA_TFLOPS
     out["note"] = "rank size (A <= 608): 95 MFLOP = 0.6 us at peak, i.e. launch-latency bound: two launches"
     return out
 

@@ -435,7 +435,8 @@ struct StripParams {
   float* slab;                         // [nchunk][A][C] dX partials (phase 4)
   float* gsym; int ldg;                // phase 4 with C > 128: Gsym written out instead
   const float* av;                     // [1] number of valid rows
-  int dbg;                             // diagnostics (DCS_CONTRAST_DBG): 1 = skip the MFMAs, 2 = skip the epilogues
+  int dbg;                             // diagnostics (DCS_CONTRAST_DBG): 1 = skip the MFMAs, 2 = skip the epilogues,
+                                       // 4 = stop after pass 1 (similarity product + statistics: bench.py times it)
 };
 
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -971,6 +972,7 @@ int launch_large(const float* X, int ldx, const float* y, int ldy, const float* 
       !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<3, 1>), strip_smem(3))) return DCS_E_LAUNCH;
   LAUNCH_STRIP(1, dim3((unsigned)nb_stats), dim3(256), strip_smem(1), s, p);
   hipLaunchKernelGGL(contrast_combine_kernel<1>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
+  if (p.dbg & 4) { DCS_LAUNCH_RET(); }      // timing of the similarity pass alone (results are not a loss)
   LAUNCH_STRIP(2, dim3((unsigned)nb_stats), dim3(256), strip_smem(2), s, p);
   hipLaunchKernelGGL(contrast_combine_kernel<2>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
   if (mode == 0) {
