@@ -76,31 +76,48 @@ class ConvProfiler:
     GEOM_ARG = {"dcs_conv_gather": 4, "dcs_conv_gather_pro": 4, "dcs_conv_gather_x3": 4, "dcs_conv3x3_x3w": 4, "dcs_conv_gather_split": 3, "dcs_conv_gather_bnbwd": 3,
                 "dcs_conv_wgrad": 3, "dcs_conv_wgrad_pro": 3, "dcs_conv_wgrad_x3": 3}   # position of the DcsConvGeom argument
 
+    MULTI = {"dcs_conv_gather_x3_multi": "dcs_conv_gather_x3", "dcs_conv3x3_x3w_multi": "dcs_conv3x3_x3w",
+             "dcs_conv_wgrad_x3_multi": "dcs_conv_wgrad_x3"}     # level-batched launches: n sub-launches in one grid
+
     def __init__(self, ops):
         self.ops, self.records, self.enabled = ops, [], False
-        self._orig = ops._call
+        self._orig = ops._call_now
+
+        def cost(g):
+            M = g.N * g.TY * g.TX
+            flops = 2.0 * M * (147 if g.stem else g.ntaps * g.K) * g.Cout
+            # algorithmic bytes: gathered tensor once + produced tensor once + weights once
+            abytes = 4.0 * (g.N * g.SH * g.SW * (3 if g.stem else g.K) + M * g.Cout + g.Cout * g.wstride)
+            return flops, abytes
 
         def wrapped(name, *args):
-            # every launch of the implicit-GEMM kernels: plain, split-K (its slab reduce is timed with it) and wgrad
-            # (also the launches with a fused BatchNorm prologue "_pro" or BatchNorm-backward epilogue "_bnbwd")
-            if self.enabled and name in self.GEOM_ARG:
-                g = args[self.GEOM_ARG[name]]._obj
-                M = g.N * g.TY * g.TX
-                flops = 2.0 * M * (147 if g.stem else g.ntaps * g.K) * g.Cout
-                # algorithmic bytes: gathered tensor once + produced tensor once + weights once
-                abytes = 4.0 * (g.N * g.SH * g.SW * (3 if g.stem else g.K) + M * g.Cout + g.Cout * g.wstride)
+            # every launch of the implicit-GEMM kernels as it reaches the library (after level batching): plain, split-K
+            # (its slab reduce is timed with it), weight gradients, with fused BatchNorm prologue "_pro" or
+            # BatchNorm-backward epilogue "_bnbwd", and the multi launches that carry the pyramid levels of one layer
+            base = self.MULTI.get(name, name)
+            if self.enabled and base in self.GEOM_ARG:
+                if name in self.MULTI:
+                    geoms = [args[0][i].geom.contents for i in range(args[1])]
+                else:
+                    ga = args[self.GEOM_ARG[name]]
+                    geoms = [getattr(ga, "_obj", ga)]
+                flops = sum(cost(g)[0] for g in geoms)
+                abytes = sum(cost(g)[1] for g in geoms)
+                g = geoms[0]
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 self._orig(name, *args)
                 e1.record()
-                kind = "dcs_conv_wgrad" if name.startswith("dcs_conv_wgrad") else "dcs_conv_gather"
-                fused = name.rsplit("_", 1)[1] if name.endswith(("_pro", "_bnbwd", "_x3", "_x3w")) else ""
+                kind = "dcs_conv_wgrad" if base.startswith("dcs_conv_wgrad") else "dcs_conv_gather"
+                fused = base.rsplit("_", 1)[1] if base.endswith(("_pro", "_bnbwd", "_x3", "_x3w")) else ""
+                if len(geoms) > 1:
+                    fused += "*%d" % len(geoms)
                 key = (kind + ("+" + fused if fused else ""), g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy,
                        g.stem)
-                self.records.append((kind, flops, e0, e1, key, abytes, name.endswith(("_x3", "_x3w"))))
+                self.records.append((kind, flops, e0, e1, key, abytes, base.endswith(("_x3", "_x3w"))))
             else:
                 self._orig(name, *args)
-        ops._call = wrapped
+        ops._call_now = wrapped
 
     def per_shape(self):
         agg = {}

@@ -58,17 +58,21 @@ __global__ void split_weight_kernel(const float* __restrict__ w, uint2* __restri
   o[0] = p1; o[4] = p2; o[8] = p3;
 }
 
+// Block coordinates of a kernel body: the hardware block id for single launches, the level-relative id inside a multi
+// launch (see the *_multi_kernel wrappers at the end of the kernels).
+struct BlkId { int x, nx, y; };
+
 constexpr int X3_ROWB = 112;      // bytes per LDS row
 
 // STEM: the 7x7 / stride 2 stem on the NHWC4 image in its 14-tap form (ops.geom_stem_fwd): a tap is a filter half-row of
 // 4 pixels x 4 channels = 16 contiguous floats = exactly one chunk; lane quad q of a row is pixel q of the tap and is
 // range-checked on its own (network/backbone/resnet_pyramid.py:110-112).
 template <int BN, int BM = 128, bool STEM = false>
-__global__ __launch_bounds__(256, 2)
-void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
-                           const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom g,
+__device__ __forceinline__
+void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
+                           const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom& g,
                            const int accumulate, const int ntiles, float* __restrict__ stats, const int cps,
-                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro) {
+                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro, const BlkId bi) {
   // 128 x 128 and 128 x 64 tiles: waves 2 x 2; 256 x 64 (64-channel layers of large maps): waves 4 x 1, so that a wave
   // still owns a 64 x 64 sub-tile (24 MFMAs per chunk against 5-6 staging slots instead of 12 against 4)
   constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = BM / (WM * 32), TN = BN / (WN * 32);
@@ -94,7 +98,7 @@ void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* _
   if (has_pro)
     for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
 
-  const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = dcs_xcd_remap(bi.x, bi.nx);
   const int ntile = bid % ntiles, mtile = bid / ntiles;
   const int co0 = ntile * BN;
   const unsigned m0 = (unsigned)mtile * BM;
@@ -151,9 +155,9 @@ void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* _
 
   const int kch = STEM ? 1 : g.K >> 4;
   const int nch = g.ntaps * kch;
-  const int cbeg = (int)blockIdx.y * cps < nch ? (int)blockIdx.y * cps : nch;
+  const int cbeg = (int)bi.y * cps < nch ? (int)bi.y * cps : nch;
   const int cend = cbeg + cps < nch ? cbeg + cps : nch;
-  dst += (long long)blockIdx.y * slab_stride;
+  dst += (long long)bi.y * slab_stride;
 
   float4 rs[NA];
   u32x4 rb[NB];
@@ -309,10 +313,10 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
 template <int BT>
-__global__ __launch_bounds__(256, 2)
-void conv_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
-                          const DcsConvGeom g, const int dy_cstride, const int split0, const long long mps,
-                          const int ciT, const float* __restrict__ pro) {
+__device__ __forceinline__
+void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                          const DcsConvGeom& g, const int dy_cstride, const int split0, const long long mps,
+                          const int ciT, const float* __restrict__ pro, const BlkId bi) {
   constexpr int T = BT / 64;             // 32x32 tiles per wave per dim
   constexpr int CHP = 16;                // pixels per chunk
   constexpr int PIECE = BT * 2;          // bytes of one piece of one pixel row
@@ -330,12 +334,12 @@ void conv_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict
   const int wm = wid >> 1, wn = wid & 1;
   const int sq = tid % Q, spx = tid / Q;     // staging: channel quad, first pixel (items: pixel spx + (256 / Q) * i)
 
-  const int bx = blockIdx.x;
+  const int bx = bi.x;
   const int t = bx % g.ntaps;
   const int rest = bx / g.ntaps;
   const int ciTile = rest % ciT, coTile = rest / ciT;
   const int co0 = coTile * BT, ci0 = ciTile * BT;
-  const int split = blockIdx.y;
+  const int split = bi.y;
   const bool odd = ((split0 + split) & 1) != 0;
 
   const long long TYX = (long long)g.TY * g.TX;
@@ -653,10 +657,10 @@ void conv_wgrad3x3_x3_kernel(const float* __restrict__ src, const float* __restr
 // three rows -- the halo lives in a ring of four row slots (row & 3: the slot of row ty+2 is free while rows ty-1..ty+1 are
 // read).  Only the first chunk of a strip (or of a split) loads three rows, behind two barriers.  Work units are
 // (image, strip, row) in that order; a split is a range of units.
-__global__ __launch_bounds__(256, 2)
-void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
-                              const DcsConvGeom g, const int dy_cstride, const int split0, const int cps, const int ciT,
-                              const float* __restrict__ pro) {
+__device__ __forceinline__
+void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                              const DcsConvGeom& g, const int dy_cstride, const int split0, const int cps, const int ciT,
+                              const float* __restrict__ pro, const BlkId bi) {
   constexpr int CHP = 16, HWP = CHP + 2;
   constexpr int PIECE = 128, ROW = 3 * PIECE + 64;             // 448 = 192 (mod 256)
   constexpr int NSX = (3 * HWP * 16 + 255) / 256;              // 256-thread passes over up to three halo rows
@@ -669,9 +673,9 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
   const int wm = wid >> 1, wn = wid & 1;
   const int lcol4 = tid & 15, lrow = tid >> 4;
 
-  const int ciTile = blockIdx.x % ciT, coTile = blockIdx.x / ciT;
+  const int ciTile = bi.x % ciT, coTile = bi.x / ciT;
   const int co0 = coTile * 64, ci0 = ciTile * 64;
-  const int split = blockIdx.y;
+  const int split = bi.y;
   const bool odd = ((split0 + split) & 1) != 0;
   const int cpr = g.TX / CHP;                           // strips per image
   const int nunits_total = g.N * cpr * g.TY;
@@ -855,9 +859,9 @@ void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __rest
 // every lane of a 16-lane group supplies its own address, so the Toeplitz structure needs no im2col copy here either.
 // Wave w owns filter rows 2w, 2w+1 (row 7 does not exist) x both 32-channel output tiles.  Odd splits: (-dy), negated
 // output (rounding-bias cancellation, see conv_wgrad_x3_kernel).
-__global__ __launch_bounds__(256, 2)
-void stem_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
-                          const DcsConvGeom g, const int dy_cstride, const int split0, const int cps) {
+__device__ __forceinline__
+void stem_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                          const DcsConvGeom& g, const int dy_cstride, const int split0, const int cps, const BlkId bi) {
   constexpr int CHP = 16, PWP = 38;                    // pixels per chunk, patch width in pixels
   constexpr int PIECE = 128, ROW = 3 * PIECE + 64;     // dy image: 448-byte rows
   constexpr int PL = PWP * 8;                          // bytes of one (filter row, piece) run: 38 px x 4 ch x 2 B = 304
@@ -868,7 +872,7 @@ void stem_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict
   const int lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int lcol4 = tid & 15, lrow = tid >> 4;
-  const int split = blockIdx.x;
+  const int split = bi.x;
   const bool odd = ((split0 + split) & 1) != 0;
   const int cpr = g.TX / CHP;
   const int nchunks_total = g.N * g.TY * cpr;
@@ -1232,11 +1236,11 @@ void conv3x3_x3_kernel(const float* __restrict__ src, const unsigned char* __res
 // the NEXT tap while it multiplies the current one; the halo is the only LDS tenant, so barriers remain only around its
 // replacement every nine taps.
 template <int BN, int TH>
-__global__ __launch_bounds__(256, 2)
-void conv3x3_x3w_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
-                        float* __restrict__ dst, const DcsConvGeom g, const int accumulate, const int ntiles,
+__device__ __forceinline__
+void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
+                        float* __restrict__ dst, const DcsConvGeom& g, const int accumulate, const int ntiles,
                         float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
-                        const unsigned neg_off) {
+                        const unsigned neg_off, const BlkId bi) {
   constexpr int BM = 32 * TH, HWD = 34, HROWS = (TH + 2) * HWD;
   constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = 2, TN = BN / (WN * 32);
   constexpr int A_BYTES = HROWS * X3_ROWB;
@@ -1260,7 +1264,7 @@ void conv3x3_x3w_kernel(const float* __restrict__ src, const unsigned char* __re
   if (has_pro)
     for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
 
-  const int bid = dcs_xcd_remap(blockIdx.x, gridDim.x);
+  const int bid = dcs_xcd_remap(bi.x, bi.nx);
   const int ntile = bid % ntiles, mtile = bid / ntiles;
   const int co0 = ntile * BN;
   const int tpx = g.TX >> 5, tpy = g.TY / TH;
@@ -1431,6 +1435,129 @@ __global__ void split_weight_frag_kernel(const float* __restrict__ w, u32x4* __r
   out[units + base] = q1 ^ f; out[units + base + 64] = q2 ^ f; out[units + base + 128] = q3 ^ f;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Kernel entry points.  Every body above runs either as its own launch or as one SUB-LAUNCH of a multi launch: the three
+// pyramid levels of a layer share every weight (network/backbone/resnet_pyramid.py:318-341) and run the same kernel on
+// maps of 1, 1/4 and 1/16 of the pixels, so one grid covers the blocks of all of them -- sub-launch i owns the hardware
+// blocks [blk0_i, blk0_i + nblk_i), blk0_i a multiple of 8 (the XCD round-robin then sees the level-relative id), and a
+// block runs exactly the code of the single launch with its level's arguments: results are bitwise those of the
+// per-level launches.  Arguments live in the kernel-argument segment; the level index is wave-uniform (scalar loads).
+constexpr int MULTI_MAX = DCS_MULTI_MAX;
+
+struct GatherSub {
+  const float* src; const unsigned char* w; const float* bias; float* dst; float* stats; const float* pro;
+  BnBwdEpi bnb;
+  long long slab_stride;
+  int accumulate, ntiles, cps, J;
+  unsigned neg_off;
+  int blk0, nbx, nblk;
+};
+struct GatherMulti { DcsConvGeom g[MULTI_MAX]; GatherSub s[MULTI_MAX]; };
+
+struct WgradSub {
+  const float* src; const float* dy; float* slab; const float* pro;
+  long long mps;
+  int dy_cstride, split0, cps, ciT;
+  int blk0, nbx, nblk;
+};
+struct WgradMulti { DcsConvGeom g[MULTI_MAX]; WgradSub s[MULTI_MAX]; };
+
+template <class MP>
+__device__ __forceinline__ int multi_level(const MP& P) {
+  int lv = 0;
+#pragma unroll
+  for (int i = 1; i < MULTI_MAX; ++i) lv += (int)blockIdx.x >= P.s[i].blk0 ? 1 : 0;     // unused entries: blk0 = INT_MAX
+  return lv;
+}
+
+#define DCS_BLK BlkId{(int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y}
+
+template <int BN, int BM = 128, bool STEM = false>
+__global__ __launch_bounds__(256, 2)
+void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
+                           const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom g,
+                           const int accumulate, const int ntiles, float* __restrict__ stats, const int cps,
+                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro) {
+  conv_gather_x3_body<BN, BM, STEM>(src, wsp, bias, dst, g, accumulate, ntiles, stats, cps, slab_stride, bnb, pro, DCS_BLK);
+}
+template <int BN, int BM = 128, bool STEM = false>
+__global__ __launch_bounds__(256, 2)
+void conv_gather_x3_multi_kernel(const GatherMulti P) {
+  const int lv = multi_level(P);
+  const GatherSub& s = P.s[lv];
+  const int rel = (int)blockIdx.x - s.blk0;
+  if (rel >= s.nblk) return;
+  conv_gather_x3_body<BN, BM, STEM>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.cps, s.slab_stride,
+                                    s.bnb, s.pro, BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
+}
+
+template <int BN, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_x3w_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
+                        float* __restrict__ dst, const DcsConvGeom g, const int accumulate, const int ntiles,
+                        float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
+                        const unsigned neg_off) {
+  conv3x3_x3w_body<BN, TH>(src, wfrag, bias, dst, g, accumulate, ntiles, stats, bnb, pro, J, neg_off, DCS_BLK);
+}
+template <int BN, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_x3w_multi_kernel(const GatherMulti P) {
+  const int lv = multi_level(P);
+  const GatherSub& s = P.s[lv];
+  const int rel = (int)blockIdx.x - s.blk0;
+  if (rel >= s.nblk) return;
+  conv3x3_x3w_body<BN, TH>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.bnb, s.pro, s.J, s.neg_off,
+                           BlkId{rel, s.nbx, 0});
+}
+
+template <int BT>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                          const DcsConvGeom g, const int dy_cstride, const int split0, const long long mps,
+                          const int ciT, const float* __restrict__ pro) {
+  conv_wgrad_x3_body<BT>(src, dy, slab, g, dy_cstride, split0, mps, ciT, pro, DCS_BLK);
+}
+template <int BT>
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad_x3_multi_kernel(const WgradMulti P) {
+  const int lv = multi_level(P);
+  const WgradSub& s = P.s[lv];
+  const int rel = (int)blockIdx.x - s.blk0;
+  if (rel >= s.nblk) return;
+  conv_wgrad_x3_body<BT>(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.mps, s.ciT, s.pro,
+                         BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
+}
+
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                              const DcsConvGeom g, const int dy_cstride, const int split0, const int cps, const int ciT,
+                              const float* __restrict__ pro) {
+  conv_wgrad3x3_x3r_body(src, dy, slab, g, dy_cstride, split0, cps, ciT, pro, DCS_BLK);
+}
+__global__ __launch_bounds__(256, 2)
+void conv_wgrad3x3_x3r_multi_kernel(const WgradMulti P) {
+  const int lv = multi_level(P);
+  const WgradSub& s = P.s[lv];
+  const int rel = (int)blockIdx.x - s.blk0;
+  if (rel >= s.nblk) return;
+  conv_wgrad3x3_x3r_body(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.cps, s.ciT, s.pro,
+                         BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
+}
+
+__global__ __launch_bounds__(256, 2)
+void stem_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
+                          const DcsConvGeom g, const int dy_cstride, const int split0, const int cps) {
+  stem_wgrad_x3_body(src, dy, slab, g, dy_cstride, split0, cps, DCS_BLK);
+}
+__global__ __launch_bounds__(256, 2)
+void stem_wgrad_x3_multi_kernel(const WgradMulti P) {
+  const int lv = multi_level(P);
+  const WgradSub& s = P.s[lv];
+  const int rel = (int)blockIdx.x - s.blk0;
+  if (rel >= s.nblk) return;
+  stem_wgrad_x3_body(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.cps, BlkId{rel, s.nbx, 0});
+}
+
 // geometries conv3x3_x3_kernel covers: the nine taps of a dense 3x3 / stride 1 / pad 1 window in any order
 bool conv3x3_halo_eligible(const DcsConvGeom* g, int th) {
   if (g->stem || g->ntaps != 9 || g->sy != 1 || g->sx != 1 || g->dsy != 1 || g->dsx != 1 || g->dy0 || g->dx0) return false;
@@ -1454,16 +1581,21 @@ extern "C" int dcs_split_weight(const float* w, void* out, int64_t rows, int wst
   DCS_LAUNCH_RET();
 }
 
-extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, float* dst,
-                                  const DcsConvGeom* geom, int accumulate, float* stats, const float* pro,
-                                  const float* bn_y, const float* bn_mask, const float* bn, int relu, int nsplit,
-                                  int64_t slab_stride, void* stream) {
+namespace {
+
+// ---- launch plans: validation + kernel choice of one (sub-)launch, shared by the single and the multi entries -----------
+enum GatherKid { GK_X3W_64, GK_X3W_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64 };
+struct GatherPlan { int kid; DcsConvGeom g; GatherSub s; unsigned nbx, nby; };
+
+int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
+  const DcsConvGeom* geom = a.geom;
   int rc = check_geom(geom);
   if (rc != DCS_OK) return rc;
-  DCS_CHECK_ARG(src && wsplit && dst && dcs_aligned16(src) && dcs_aligned16(wsplit));
+  const int nsplit = a.nsplit;
+  DCS_CHECK_ARG(a.src && a.wgt && a.dst && dcs_aligned16(a.src) && dcs_aligned16(a.wgt));
   DCS_CHECK_ARG(geom->dst_cstride >= geom->Cout && nsplit >= 1 && nsplit <= 64);
   // what this kernel family covers; everything else stays on dcs_conv_gather
-  const bool stem14 = geom->stem && geom->ntaps == 14 && geom->Cout == 64 && geom->wstride == 224 && !pro && nsplit == 1;
+  const bool stem14 = geom->stem && geom->ntaps == 14 && geom->Cout == 64 && geom->wstride == 224 && !a.pro && nsplit == 1;
   if ((geom->stem && !stem14) || geom->Cout <= 32 || (!geom->stem && (geom->K & 15)) || (geom->wstride & 15))
     return DCS_E_UNSUPPORTED;
   for (int t = 0; t < geom->ntaps; ++t)
@@ -1478,25 +1610,28 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
     if (span * img_bytes > 0x7FFFFFFFll || (long long)geom->Cout * geom->wstride * 6 > 0x7FFFFFFFll)
       return DCS_E_UNSUPPORTED;
   }
-  const BnBwdEpi bnb{bn_y, bn_mask, bn, relu};
-  DCS_CHECK_ARG(!(stats && accumulate && !bnb.y));
-  DCS_CHECK_ARG(!pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(pro)));
-  DCS_CHECK_ARG(!bnb.y || (stats && bnb.bn && nsplit == 1 && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
-                           dcs_aligned16(dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
+  const BnBwdEpi bnb{a.bn_y, a.bn_mask, a.bn, a.relu};
+  DCS_CHECK_ARG(!(a.stats && a.accumulate && !bnb.y));
+  DCS_CHECK_ARG(!a.pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(a.pro)));
+  DCS_CHECK_ARG(!bnb.y || (a.stats && bnb.bn && nsplit == 1 && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
+                           dcs_aligned16(a.dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
   if (nsplit > 1)
-    DCS_CHECK_ARG(!bias && !stats && !accumulate && slab_stride >= M * geom->dst_cstride);
+    DCS_CHECK_ARG(!a.bias && !a.stats && !a.accumulate && a.slab_stride >= M * geom->dst_cstride);
   const int bn_ = geom->Cout > 64 ? 128 : 64;
   const int ntiles = (geom->Cout + bn_ - 1) / bn_;
   // 64-wide layers of large maps: 256-pixel tiles (enough of them to fill the chip several times over)
   const bool bm256 = bn_ == 64 && nsplit == 1 && M >= 256ll * 2048 && getenv("DCS_X3_BM128") == nullptr;
   const long long blocks = (bm256 ? (M + 255) / 256 : (M + 127) / 128) * ntiles;
-  DCS_CHECK_ARG(blocks > 0 && blocks < (1ll << 31));
+  DCS_CHECK_ARG(blocks > 0 && blocks * nsplit < (1ll << 30));
   const int nch = geom->ntaps * (geom->stem ? 1 : geom->K >> 4);
   // an even number of chunks per K split: every split then pairs its +A and -A chunks (the bias cancellation of the kernel)
   int cps = (nch + nsplit - 1) / nsplit;
   if (nsplit > 1) cps += cps & 1;
-  hipStream_t s = dcs_stream(stream);
-  const unsigned char* wsp = reinterpret_cast<const unsigned char*>(wsplit);
+  P.g = *geom;
+  P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), a.bias, a.dst, a.stats, a.pro, bnb,
+                  (long long)a.slab_stride, a.accumulate, ntiles, cps, 0, 0u, 0, 0, 0};
+  P.nbx = (unsigned)blocks;
+  P.nby = (unsigned)nsplit;
   // DCS_X3_HALO=0: never; =2: whenever the geometry allows (tests: small shapes); default: when there are enough tiles
   const char* halo_env = getenv("DCS_X3_HALO");                  // read per launch: the tests flip it
   const bool g_halo = halo_env == nullptr || halo_env[0] != '0';
@@ -1504,54 +1639,175 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
   if (g_halo && nsplit == 1 && (long long)geom->SH * geom->SW * geom->src_cstride * 4 <= 0x7FFFFFFFll) {
     // enough tiles to fill the chip twice over, else the per-tap kernel (and its K splits) does better
     if (bn_ == 64 && conv3x3_halo_eligible(geom, 8) && (g_halo_force || M >= 256ll * 1024)) {
-      hipLaunchKernelGGL((conv3x3_x3_kernel<64, 8>), dim3((unsigned)((M / 256) * ntiles)), dim3(256), 0, s, src, wsp, bias, dst,
-                         *geom, accumulate, ntiles, stats, bnb, pro);
-      DCS_LAUNCH_RET();
+      P.kid = GK_HALO_64; P.nbx = (unsigned)((M / 256) * ntiles);
+      return DCS_OK;
     }
     if (bn_ == 128 && conv3x3_halo_eligible(geom, 4) && (g_halo_force || (M / 128) * ntiles >= 1024)) {
-      hipLaunchKernelGGL((conv3x3_x3_kernel<128, 4>), dim3((unsigned)((M / 128) * ntiles)), dim3(256), 0, s, src, wsp, bias, dst,
-                         *geom, accumulate, ntiles, stats, bnb, pro);
-      DCS_LAUNCH_RET();
+      P.kid = GK_HALO_128; P.nbx = (unsigned)((M / 128) * ntiles);
+      return DCS_OK;
     }
   }
-  if (geom->stem) {
-    if (bm256)
-      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256, true>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, src, wsp, bias,
-                         dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
-    else
-      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 128, true>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, src, wsp, bias,
-                         dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
-    DCS_LAUNCH_RET();
-  }
-  if (bn_ == 128)
-    hipLaunchKernelGGL(conv_gather_x3_kernel<128>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, wsp, bias,
-                       dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
-  else if (bm256)
-    hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256>), dim3((unsigned)blocks, 1u), dim3(256), 0, s, src, wsp, bias, dst,
-                       *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
-  else
-    hipLaunchKernelGGL(conv_gather_x3_kernel<64>, dim3((unsigned)blocks, (unsigned)nsplit), dim3(256), 0, s, src, wsp, bias,
-                       dst, *geom, accumulate, ntiles, stats, cps, (long long)slab_stride, bnb, pro);
-  DCS_LAUNCH_RET();
+  if (geom->stem) P.kid = bm256 ? GK_STEM_256 : GK_STEM_128;
+  else if (bn_ == 128) P.kid = GK_128;
+  else P.kid = bm256 ? GK_64_256 : GK_64;
+  if (P.kid != GK_128 && P.kid != GK_64) DCS_CHECK_ARG(nsplit == 1);
+  return DCS_OK;
 }
 
-extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
-                                 int split0, int nsplit, const float* pro, void* stream) {
+int plan_x3w(const DcsGatherLaunch& a, GatherPlan& P) {
+  const DcsConvGeom* geom = a.geom;
   int rc = check_geom(geom);
   if (rc != DCS_OK) return rc;
-  DCS_CHECK_ARG(src && dy && slab && dcs_aligned16(src) && dcs_aligned16(dy) && (!pro || dcs_aligned16(pro)));
-  DCS_CHECK_ARG((dy_cstride & 3) == 0 && dy_cstride >= geom->Cout && nsplit > 0 && split0 >= 0);
+  DCS_CHECK_ARG(a.src && a.wgt && a.dst && dcs_aligned16(a.src) && dcs_aligned16(a.wgt) && geom->dst_cstride >= geom->Cout);
+  DCS_CHECK_ARG(a.nsplit <= 1);
+  const int bn_ = geom->Cout > 64 ? 128 : 64;
+  const int th = bn_ == 64 ? 8 : 4;
+  if (geom->Cout <= 32 || (geom->wstride & 15) || !conv3x3_halo_eligible(geom, th)) return DCS_E_UNSUPPORTED;
+  for (int t = 0; t < 9; ++t)
+    if (geom->wofs[t] & 15) return DCS_E_UNSUPPORTED;
+  if ((long long)geom->SH * geom->SW * geom->src_cstride * 4 > 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
+  const BnBwdEpi bnb{a.bn_y, a.bn_mask, a.bn, a.relu};
+  DCS_CHECK_ARG(!(a.stats && a.accumulate && !bnb.y));
+  DCS_CHECK_ARG(!a.pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(a.pro)));
+  DCS_CHECK_ARG(!bnb.y || (a.stats && bnb.bn && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
+                           dcs_aligned16(a.dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
+  const long long M = (long long)geom->N * geom->TY * geom->TX;
+  DCS_CHECK_ARG(M < 0x7FFFFF00ll);
+  const int ntiles = (geom->Cout + bn_ - 1) / bn_;
+  const int J = (geom->Cout + 31) / 32;
+  const long long units = (long long)(geom->wstride >> 4) * J * 3 * 64;
+  P.g = *geom;
+  P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), a.bias, a.dst, a.stats, a.pro, bnb, 0ll,
+                  a.accumulate, ntiles, 0, J, (unsigned)(units * 16), 0, 0, 0};
+  P.kid = bn_ == 64 ? GK_X3W_64 : GK_X3W_128;
+  P.nbx = (unsigned)((M / (bn_ == 64 ? 256 : 128)) * ntiles);
+  P.nby = 1;
+  return DCS_OK;
+}
+
+#define DCS_GATHER_ARGS(P) (P).s.src, (P).s.w, (P).s.bias, (P).s.dst, (P).g, (P).s.accumulate, (P).s.ntiles, (P).s.stats
+int launch_gather_one(const GatherPlan& P, hipStream_t s) {
+  const dim3 grid(P.nbx, P.nby), blk(256);
+  switch (P.kid) {
+    case GK_X3W_64:
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      break;
+    case GK_X3W_128:
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      break;
+    case GK_HALO_64:
+      hipLaunchKernelGGL((conv3x3_x3_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro);
+      break;
+    case GK_HALO_128:
+      hipLaunchKernelGGL((conv3x3_x3_kernel<128, 4>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro);
+      break;
+    case GK_STEM_256:
+      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256, true>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride,
+                         P.s.bnb, P.s.pro);
+      break;
+    case GK_STEM_128:
+      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 128, true>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride,
+                         P.s.bnb, P.s.pro);
+      break;
+    case GK_128:
+      hipLaunchKernelGGL(conv_gather_x3_kernel<128>, grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride, P.s.bnb,
+                         P.s.pro);
+      break;
+    case GK_64_256:
+      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride,
+                         P.s.bnb, P.s.pro);
+      break;
+    default:
+      hipLaunchKernelGGL(conv_gather_x3_kernel<64>, grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride, P.s.bnb,
+                         P.s.pro);
+  }
+  return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;
+}
+
+// block ranges of the sub-launches: starts padded to multiples of 8 (one round of the XCD round-robin)
+template <class MP, class PL>
+long long pack_multi(MP& mp, const PL* const* plans, int n) {
+  long long at = 0;
+  for (int i = 0; i < MULTI_MAX; ++i) {
+    if (i < n) {
+      mp.g[i] = plans[i]->g;
+      mp.s[i] = plans[i]->s;
+      mp.s[i].blk0 = (int)at;
+      mp.s[i].nbx = (int)plans[i]->nbx;
+      mp.s[i].nblk = (int)(plans[i]->nbx * plans[i]->nby);
+      at += ((long long)mp.s[i].nblk + 7) / 8 * 8;
+    } else {
+      mp.g[i] = mp.g[0];
+      mp.s[i] = mp.s[0];
+      mp.s[i].blk0 = 0x7FFFFFFF;
+      mp.s[i].nblk = 0;
+    }
+  }
+  return at;
+}
+
+// same-kernel plans (n >= 2) as one launch
+int launch_gather_multi(const GatherPlan* const* plans, int n, hipStream_t s) {
+  GatherMulti mp;
+  const long long total = pack_multi(mp, plans, n);
+  if (total <= 0 || total >= (1ll << 31)) return DCS_E_ARG;
+  const dim3 grid((unsigned)total), blk(256);
+  switch (plans[0]->kid) {
+    case GK_X3W_64: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<64, 8>), grid, blk, 0, s, mp); break;
+    case GK_X3W_128: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4>), grid, blk, 0, s, mp); break;
+    case GK_STEM_256: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, true>), grid, blk, 0, s, mp); break;
+    case GK_STEM_128: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, true>), grid, blk, 0, s, mp); break;
+    case GK_128: hipLaunchKernelGGL(conv_gather_x3_multi_kernel<128>, grid, blk, 0, s, mp); break;
+    case GK_64_256: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256>), grid, blk, 0, s, mp); break;
+    case GK_64: hipLaunchKernelGGL(conv_gather_x3_multi_kernel<64>, grid, blk, 0, s, mp); break;
+    default: return DCS_E_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;
+}
+
+bool gather_kid_batches(int kid) { return kid != GK_HALO_64 && kid != GK_HALO_128; }
+
+// n validated plans -> launches: plans that chose the same kernel share one grid, the others go out on their own
+int launch_gather_plans(const GatherPlan* plans, int n, hipStream_t s) {
+  bool done[DCS_MULTI_MAX] = {};
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    const GatherPlan* grp[DCS_MULTI_MAX];
+    int m = 0;
+    grp[m++] = &plans[i];
+    done[i] = true;
+    if (gather_kid_batches(plans[i].kid))
+      for (int j = i + 1; j < n; ++j)
+        if (!done[j] && plans[j].kid == plans[i].kid) { grp[m++] = &plans[j]; done[j] = true; }
+    const int rc = m == 1 ? launch_gather_one(*grp[0], s) : launch_gather_multi(grp, m, s);
+    if (rc != DCS_OK) return rc;
+  }
+  return DCS_OK;
+}
+
+enum WgradKid { WK_STEM, WK_ROLL, WK_NINE, WK_128, WK_64 };
+struct WgradPlan { int kid; DcsConvGeom g; WgradSub s; unsigned nbx, nby; };
+
+int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
+  const DcsConvGeom* geom = a.geom;
+  const int dy_cstride = a.dy_cstride, nsplit = a.nsplit, split0 = a.split0;
+  int rc = check_geom(geom);
+  if (rc != DCS_OK) return rc;
+  DCS_CHECK_ARG(a.src && a.dy && a.slab && dcs_aligned16(a.src) && dcs_aligned16(a.dy) && (!a.pro || dcs_aligned16(a.pro)));
+  DCS_CHECK_ARG((dy_cstride & 3) == 0 && dy_cstride >= geom->Cout && nsplit > 0 && nsplit < 65536 && split0 >= 0);
   DCS_CHECK_ARG(geom->dsy == 1 && geom->dsx == 1 && geom->dy0 == 0 && geom->dx0 == 0 &&
                 geom->TY == geom->DH && geom->TX == geom->DW);
+  P.g = *geom;
+  P.s = WgradSub{a.src, a.dy, a.slab, a.pro, 0ll, dy_cstride, split0, 0, 0, 0, 0, 0};
+  P.nby = (unsigned)nsplit;
   if (geom->stem) {                    // the seven-tap stem geometry (ops.geom_stem): its own kernel
-    if ((geom->TX & 15) || geom->Cout != 64 || geom->wstride != 224 || geom->ntaps != 7 || pro) return DCS_E_UNSUPPORTED;
+    if ((geom->TX & 15) || geom->Cout != 64 || geom->wstride != 224 || geom->ntaps != 7 || a.pro) return DCS_E_UNSUPPORTED;
     const long long nchunks = (long long)geom->N * geom->TY * (geom->TX / 16);
     const int cps = (int)((nchunks + nsplit - 1) / nsplit);
     const long long span = ((long long)cps * 32 + 8ll * geom->SW) * 16;
     if ((long long)cps * 16 * dy_cstride * 4 >= 0x7FFFFFFFll || span >= 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
-    hipLaunchKernelGGL(stem_wgrad_x3_kernel, dim3((unsigned)nsplit), dim3(256), 0, dcs_stream(stream), src, dy, slab, *geom,
-                       dy_cstride, split0, cps);
-    DCS_LAUNCH_RET();
+    P.kid = WK_STEM; P.s.cps = cps; P.nbx = (unsigned)nsplit; P.nby = 1;
+    return DCS_OK;
   }
   if (geom->Cout & 3) return DCS_E_UNSUPPORTED;
   const long long M = (long long)geom->N * geom->TY * geom->TX;
@@ -1559,12 +1815,12 @@ extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab,
   mps = (mps + 31) / 32 * 32;
   const long long span_src = (mps * geom->sy * geom->sx + 4ll * geom->SW) * geom->src_cstride * 4;
   if (mps * (long long)dy_cstride * 4 >= 0x7FFFFFFFll || span_src >= 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
-  hipStream_t s = dcs_stream(stream);
   if (wgrad3x3_x3_eligible(geom)) {
     const long long nchunks = (long long)geom->N * geom->TY * (geom->TX / 16);
     const int cps = (int)((nchunks + nsplit - 1) / nsplit);
     const int coT = (geom->Cout + 63) / 64, ciT = (geom->K + 63) / 64;
     const long long span = ((long long)cps * 16 + 4ll * geom->SW) * geom->src_cstride * 4;
+    P.s.cps = cps; P.s.ciT = ciT; P.nbx = (unsigned)(coT * ciT);
     {
       // rolling-window kernel: units are (image, strip, row); a split may reach into the following image(s)
       const long long per_img = (long long)geom->TY * (geom->TX / 16);
@@ -1574,25 +1830,106 @@ extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab,
       const long long dbytes = imgs * geom->TY * geom->TX * dy_cstride * 4;
       const char* roll = getenv("DCS_WGRAD_ROLL");
       if ((roll == nullptr || roll[0] != '0') && xbytes < 0x7FFFFFFFll && dbytes < 0x7FFFFFFFll) {
-        hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0, s, src, dy,
-                           slab, *geom, dy_cstride, split0, cps, ciT, pro);
-        DCS_LAUNCH_RET();
+        P.kid = WK_ROLL;
+        return DCS_OK;
       }
     }
     if ((long long)cps * 16 * dy_cstride * 4 < 0x7FFFFFFFll && span < 0x7FFFFFFFll) {
-      hipLaunchKernelGGL(conv_wgrad3x3_x3_kernel, dim3((unsigned)(coT * ciT), (unsigned)nsplit), dim3(256), 0, s, src, dy,
-                         slab, *geom, dy_cstride, split0, cps, ciT, pro);
-      DCS_LAUNCH_RET();
+      P.kid = WK_NINE;
+      return DCS_OK;
     }
   }
   const int bt = (geom->Cout > 64 && geom->K > 64) ? 128 : 64;
   const int coT = (geom->Cout + bt - 1) / bt, ciT = (geom->K + bt - 1) / bt;
-  dim3 grid((unsigned)(geom->ntaps * coT * ciT), (unsigned)nsplit);
-  if (bt == 128)
-    hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT, pro);
-  else
-    hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, dim3(256), 0, s, src, dy, slab, *geom, dy_cstride, split0, mps, ciT, pro);
-  DCS_LAUNCH_RET();
+  P.kid = bt == 128 ? WK_128 : WK_64;
+  P.s.mps = mps; P.s.ciT = ciT; P.s.cps = 0;
+  P.nbx = (unsigned)(geom->ntaps * coT * ciT);
+  return DCS_OK;
+}
+
+#define DCS_WGRAD_ARGS(P) (P).s.src, (P).s.dy, (P).s.slab, (P).g, (P).s.dy_cstride, (P).s.split0
+int launch_wgrad_one(const WgradPlan& P, hipStream_t s) {
+  const dim3 grid(P.nbx, P.nby), blk(256);
+  switch (P.kid) {
+    case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps); break;
+    case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro); break;
+    case WK_NINE: hipLaunchKernelGGL(conv_wgrad3x3_x3_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro); break;
+    case WK_128: hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro); break;
+    default: hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro);
+  }
+  return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;
+}
+
+int launch_wgrad_multi(const WgradPlan* const* plans, int n, hipStream_t s) {
+  WgradMulti mp;
+  const long long total = pack_multi(mp, plans, n);
+  if (total <= 0 || total >= (1ll << 31)) return DCS_E_ARG;
+  const dim3 grid((unsigned)total), blk(256);
+  switch (plans[0]->kid) {
+    case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_multi_kernel, grid, blk, 0, s, mp); break;
+    case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_multi_kernel, grid, blk, 0, s, mp); break;
+    case WK_128: hipLaunchKernelGGL(conv_wgrad_x3_multi_kernel<128>, grid, blk, 0, s, mp); break;
+    case WK_64: hipLaunchKernelGGL(conv_wgrad_x3_multi_kernel<64>, grid, blk, 0, s, mp); break;
+    default: return DCS_E_ARG;
+  }
+  return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;
+}
+
+int launch_wgrad_plans(const WgradPlan* plans, int n, hipStream_t s) {
+  bool done[DCS_MULTI_MAX] = {};
+  for (int i = 0; i < n; ++i) {
+    if (done[i]) continue;
+    const WgradPlan* grp[DCS_MULTI_MAX];
+    int m = 0;
+    grp[m++] = &plans[i];
+    done[i] = true;
+    if (plans[i].kid != WK_NINE)
+      for (int j = i + 1; j < n; ++j)
+        if (!done[j] && plans[j].kid == plans[i].kid) { grp[m++] = &plans[j]; done[j] = true; }
+    const int rc = m == 1 ? launch_wgrad_one(*grp[0], s) : launch_wgrad_multi(grp, m, s);
+    if (rc != DCS_OK) return rc;
+  }
+  return DCS_OK;
+}
+
+}  // namespace
+
+extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, float* dst,
+                                  const DcsConvGeom* geom, int accumulate, float* stats, const float* pro,
+                                  const float* bn_y, const float* bn_mask, const float* bn, int relu, int nsplit,
+                                  int64_t slab_stride, void* stream) {
+  const DcsGatherLaunch a{src, wsplit, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, slab_stride, accumulate, relu, nsplit};
+  GatherPlan P;
+  const int rc = plan_gather_x3(a, P);
+  return rc != DCS_OK ? rc : launch_gather_one(P, dcs_stream(stream));
+}
+
+extern "C" int dcs_conv_gather_x3_multi(const DcsGatherLaunch* launches, int n, void* stream) {
+  DCS_CHECK_ARG(launches && n >= 1 && n <= DCS_MULTI_MAX);
+  GatherPlan P[DCS_MULTI_MAX];
+  for (int i = 0; i < n; ++i) {                 // nothing is launched unless every sub-launch is valid
+    const int rc = plan_gather_x3(launches[i], P[i]);
+    if (rc != DCS_OK) return rc;
+  }
+  return launch_gather_plans(P, n, dcs_stream(stream));
+}
+
+extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
+                                 int split0, int nsplit, const float* pro, void* stream) {
+  const DcsWgradLaunch a{src, dy, slab, geom, pro, dy_cstride, split0, nsplit};
+  WgradPlan P;
+  const int rc = plan_wgrad_x3(a, P);
+  return rc != DCS_OK ? rc : launch_wgrad_one(P, dcs_stream(stream));
+}
+
+extern "C" int dcs_conv_wgrad_x3_multi(const DcsWgradLaunch* launches, int n, void* stream) {
+  DCS_CHECK_ARG(launches && n >= 1 && n <= DCS_MULTI_MAX);
+  WgradPlan P[DCS_MULTI_MAX];
+  for (int i = 0; i < n; ++i) {
+    const int rc = plan_wgrad_x3(launches[i], P[i]);
+    if (rc != DCS_OK) return rc;
+  }
+  return launch_wgrad_plans(P, n, dcs_stream(stream));
 }
 
 extern "C" int dcs_split_weight_frag(const float* w, void* out, int64_t rows, int wstride, void* stream) {
@@ -1610,31 +1947,18 @@ extern "C" int dcs_split_weight_frag(const float* w, void* out, int64_t rows, in
 extern "C" int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, float* dst, const DcsConvGeom* geom,
                                int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
                                const float* bn, int relu, void* stream) {
-  int rc = check_geom(geom);
-  if (rc != DCS_OK) return rc;
-  DCS_CHECK_ARG(src && wfrag && dst && dcs_aligned16(src) && dcs_aligned16(wfrag) && geom->dst_cstride >= geom->Cout);
-  const int bn_ = geom->Cout > 64 ? 128 : 64;
-  const int th = bn_ == 64 ? 8 : 4;
-  if (geom->Cout <= 32 || (geom->wstride & 15) || !conv3x3_halo_eligible(geom, th)) return DCS_E_UNSUPPORTED;
-  for (int t = 0; t < 9; ++t)
-    if (geom->wofs[t] & 15) return DCS_E_UNSUPPORTED;
-  if ((long long)geom->SH * geom->SW * geom->src_cstride * 4 > 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
-  const BnBwdEpi bnb{bn_y, bn_mask, bn, relu};
-  DCS_CHECK_ARG(!(stats && accumulate && !bnb.y));
-  DCS_CHECK_ARG(!pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(pro)));
-  DCS_CHECK_ARG(!bnb.y || (stats && bnb.bn && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout && dcs_aligned16(dst) &&
-                           dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
-  const long long M = (long long)geom->N * geom->TY * geom->TX;
-  const int ntiles = (geom->Cout + bn_ - 1) / bn_;
-  const int J = (geom->Cout + 31) / 32;
-  const long long units = (long long)(geom->wstride >> 4) * J * 3 * 64;
-  hipStream_t s = dcs_stream(stream);
-  const unsigned char* wf = reinterpret_cast<const unsigned char*>(wfrag);
-  if (bn_ == 64)
-    hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8>), dim3((unsigned)((M / 256) * ntiles)), dim3(256), 0, s, src, wf, bias, dst,
-                       *geom, accumulate, ntiles, stats, bnb, pro, J, (unsigned)(units * 16));
-  else
-    hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4>), dim3((unsigned)((M / 128) * ntiles)), dim3(256), 0, s, src, wf, bias, dst,
-                       *geom, accumulate, ntiles, stats, bnb, pro, J, (unsigned)(units * 16));
-  DCS_LAUNCH_RET();
+  const DcsGatherLaunch a{src, wfrag, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, 0, accumulate, relu, 1};
+  GatherPlan P;
+  const int rc = plan_x3w(a, P);
+  return rc != DCS_OK ? rc : launch_gather_one(P, dcs_stream(stream));
+}
+
+extern "C" int dcs_conv3x3_x3w_multi(const DcsGatherLaunch* launches, int n, void* stream) {
+  DCS_CHECK_ARG(launches && n >= 1 && n <= DCS_MULTI_MAX);
+  GatherPlan P[DCS_MULTI_MAX];
+  for (int i = 0; i < n; ++i) {
+    const int rc = plan_x3w(launches[i], P[i]);
+    if (rc != DCS_OK) return rc;
+  }
+  return launch_gather_plans(P, n, dcs_stream(stream));
 }

@@ -21,6 +21,23 @@ class DcsConvGeom(C.Structure):
         ("offy", C.c_int16 * MAX_TAPS), ("offx", C.c_int16 * MAX_TAPS), ("wofs", C.c_int32 * MAX_TAPS)]
 
 
+MULTI_MAX = 3             # DCS_MULTI_MAX
+
+
+class DcsGatherLaunch(C.Structure):
+    """One sub-launch of dcs_conv_gather_x3_multi / dcs_conv3x3_x3w_multi (include/dcs_hip.h)."""
+    _fields_ = [("src", C.c_void_p), ("wgt", C.c_void_p), ("bias", C.c_void_p), ("dst", C.c_void_p),
+                ("geom", C.POINTER(DcsConvGeom)), ("stats", C.c_void_p), ("pro", C.c_void_p), ("bn_y", C.c_void_p),
+                ("bn_mask", C.c_void_p), ("bn", C.c_void_p), ("slab_stride", C.c_int64), ("accumulate", C.c_int32),
+                ("relu", C.c_int32), ("nsplit", C.c_int32)]
+
+
+class DcsWgradLaunch(C.Structure):
+    """One sub-launch of dcs_conv_wgrad_x3_multi."""
+    _fields_ = [("src", C.c_void_p), ("dy", C.c_void_p), ("slab", C.c_void_p), ("geom", C.POINTER(DcsConvGeom)),
+                ("pro", C.c_void_p), ("dy_cstride", C.c_int32), ("split0", C.c_int32), ("nsplit", C.c_int32)]
+
+
 _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
@@ -39,6 +56,9 @@ SIGNATURES = {
     "dcs_split_weight_frag": [_P, _P, _L, _I, _P],
     "dcs_conv3x3_x3w": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _P],
     "dcs_conv_wgrad_x3": [_P, _P, _P, _G, _I, _I, _I, _P, _P],
+    "dcs_conv_gather_x3_multi": [C.POINTER(DcsGatherLaunch), _I, _P],
+    "dcs_conv3x3_x3w_multi": [C.POINTER(DcsGatherLaunch), _I, _P],
+    "dcs_conv_wgrad_x3_multi": [C.POINTER(DcsWgradLaunch), _I, _P],
     "dcs_conv_gather_pro": [_P, _P, _P, _P, _G, _I, _P, _P, _I, _L, _P],
     "dcs_conv_wgrad_pro": [_P, _P, _P, _G, _I, _I, _I, _P, _P],
     "dcs_reduce_slab": [_P, _P, _L, _I, _I, _I, _I, _P],

@@ -249,22 +249,39 @@ class SwiftNetEngine:
         H, W = parts[0].shape[2:]
         pyr = ops.normalize_pyramid(parts if len(parts) > 1 else parts[0], self._mean, self._std)
         wst = ops.pack_stem_weight(fe.conv1.weight)
-        skips: List[List[torch.Tensor]] = [[] for _ in range(6)]
-        for idx, p in enumerate(pyr):
-            bnm = getattr(fe, f"bn1_{idx}")
-            y, st = ops.stem_conv(p, wst, want_stats=True) if training else (ops.stem_conv(p, wst), None)
-            bn = self._bn(y, bnm, training, sums=st)
-            x, pidx = ops.bn_relu_maxpool(y, bn)
-            if need_grad:
-                tape.append(("stem", idx, p, y, bn, pidx, bnm))
+        # The levels run in LOCKSTEP (stem, then block by block): inside ops.level_batch the convolutions the levels have in
+        # common go out as one launch per layer.  Each level keeps its own tape (same item order as a level-by-level run).
+        nl = len(pyr)
+        ltapes: List[list] = [[] for _ in range(nl)] if need_grad else None
+        skips: List[List[tuple]] = [[] for _ in range(6)]
+        xs: List[torch.Tensor] = [None] * nl
+        with ops.level_batch() as lb:
+            for idx, p in enumerate(pyr):
+                lb.level(idx)
+                bnm = getattr(fe, f"bn1_{idx}")
+                y, st = ops.stem_conv(p, wst, want_stats=True) if training else (ops.stem_conv(p, wst), None)
+                bn = self._bn(y, bnm, training, sums=st)
+                xs[idx], pidx = ops.bn_relu_maxpool(y, bn)
+                if need_grad:
+                    ltapes[idx].append(("stem", idx, p, y, bn, pidx, bnm))
+            lb.flush()
             for li, (lname, planes, stride) in enumerate(LAYERS):
                 for blk in getattr(fe, lname):
-                    x = self._block_fwd(x, blk, training, tape)
+                    for idx in range(nl):
+                        lb.level(idx)
+                        xs[idx] = self._block_fwd(xs[idx], blk, training, ltapes[idx] if need_grad else None)
+                    lb.flush()
                 bott = getattr(fe, f"upsample_bottlenecks{li + 1}")
-                s = ops.conv_fwd(x, bott.weight, 1, 0)
-                if need_grad:
-                    tape.append(("skip", idx + li, x, bott))
-                skips[idx + li].append(s)
+                for idx in range(nl):
+                    lb.level(idx)
+                    s = ops.conv_fwd(xs[idx], bott.weight, 1, 0)
+                    if need_grad:
+                        ltapes[idx].append(("skip", idx + li, xs[idx], bott))
+                    skips[idx + li].append((idx, s))
+                lb.flush()
+        skips = [[t for _, t in sorted(sk, key=lambda e: e[0])] for sk in skips]       # level order, as level-by-level
+        if need_grad:
+            tape.append(("levels", ltapes))
         skips = skips[::-1]
         x = skips[0][0]
         for i in range(1, 6):
@@ -413,78 +430,92 @@ class SwiftNetEngine:
             g_skip[5 - i] = g_t                      # skips[idx + li] with idx + li = 5 - i
             g_x = ops.upsample_bwd(g_t, in_hw[0], in_hw[1])
         g_skip[5] = g_x                              # coarsest map: level 2, layer4
-        # ---- encoder, pyramid levels in reverse creation order ----
-        g_cur = None
-        cur_sums = None                # BatchNorm-backward sums of g_cur for the block that consumes it next (or None)
+        # ---- encoder: the levels in lockstep (reverse creation order inside every step, like a level-by-level walk of
+        # the tape: the shared weights and BatchNorm parameters accumulate their gradients in the same order) ----
         dwst = None
+        if pos >= 0:
+            assert tape[pos][0] == "levels" and pos == 0
+            ltapes = tape[pos][1]
+            nl = len(ltapes)
+            steps = len(ltapes[0])
+            assert all(len(t) == steps for t in ltapes)
+            g_curs = [None] * nl
+            sums_l = [None] * nl       # BatchNorm-backward sums of g_cur for the block that consumes it next (or None)
 
-        def consumer_bnb():
-            """The next tape item, if it is a block: g_cur written now is final and goes into that block's bn2 backward
-            (mask = sign of the block output): its two sums can ride the epilogue of the kernel that writes g_cur last."""
-            if pos >= 0 and tape[pos][0] == "block":
-                _, _, _, _, _, _, y2n, bn2n, _, _, outn = tape[pos]
-                return (y2n, outn, bn2n, False)
-            return None
+            def consumer_bnb(lt, at):
+                """The next tape item of the level, if it is a block: g_cur written now is final and goes into that
+                block's bn2 backward (mask = sign of the block output): its two sums can ride the epilogue of the kernel
+                that writes g_cur last."""
+                if at >= 0 and lt[at][0] == "block":
+                    _, _, _, _, _, _, y2n, bn2n, _, _, outn = lt[at]
+                    return (y2n, outn, bn2n, False)
+                return None
 
-        while pos >= 0:
-            item = tape[pos]
-            pos -= 1
-            kind = item[0]
-            if kind == "skip":
-                _, lvl, x, bott = item
-                gs = g_skip[lvl]
-                wgrad(bott, x, gs, 1, 0)
-                # the skip projection's data gradient is the LAST writer of the gradient of this layer's output
-                cb = consumer_bnb()
-                if g_cur is None:
-                    r = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, bnb=cb)
-                else:
-                    r = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, out=g_cur, accumulate=True, bnb=cb)
-                g_cur, cur_sums = r if cb is not None else (r, None)
-            elif kind == "block":
-                _, blk, x, y1, bn1, z1, y2, bn2, yd, bnd, out = item
-                s = blk.stride
-                dy2, gm = bn_bwd(blk.bn2, g_cur, y2, bn2, masksrc=out, want_gm=True, sums=cur_sums)
-                cur_sums = None
-                if training:       # activation-checkpoint recompute side effect (SURVEY.md N3)
-                    ops.bn_ema_again(bn2, blk.bn2.running_mean, blk.bn2.running_var, y2.numel() // y2.shape[-1],
-                                     momentum=blk.bn2.momentum)
-                    self._nbt.append(blk.bn2)
-                wgrad(blk.conv2, z1, dy2, 1, 1, pro_of(z1, y1, bn1))
-                g_z1, s1 = ops.conv_dgrad(dy2, wp(blk.conv2), z1.shape[1:3], 1, 1, bnb=(y1, None, bn1, True))
-                dy1, _ = bn_bwd(blk.bn1, g_z1, y1, bn1, relu=True, sums=s1)
-                if training:
-                    ops.bn_ema_again(bn1, blk.bn1.running_mean, blk.bn1.running_var, y1.numel() // y1.shape[-1],
-                                     momentum=blk.bn1.momentum)
-                    self._nbt.append(blk.bn1)
-                wgrad(blk.conv1, x, dy1, s, 1)
-                if blk.downsample is not None:
-                    dyd, _ = bn_bwd(blk.downsample[1], gm, yd, bnd)
-                    wgrad(blk.downsample[0], x, dyd, s, 0)
-                    g_in = ops.conv_dgrad(dyd, wp(blk.downsample[0]), x.shape[1:3], s, 0)
-                else:
-                    g_in = gm
-                # conv1's data gradient is the last writer of this block's input gradient unless a skip projection
-                # follows (first block of a layer: the next tape item is then "skip", not "block")
-                cb = consumer_bnb()
-                r = ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1, out=g_in, accumulate=True, bnb=cb)
-                g_cur, cur_sums = r if cb is not None else (r, None)
-            elif kind == "stem":
-                _, idx, p, y, bn, pidx, bnm = item
-                acc = bnm.weight in grads
-                if not acc:
-                    grads[bnm.weight] = self._galloc(bnm.weight)
-                    grads[bnm.bias] = self._galloc(bnm.bias)
-                dy = ops.bn_pool_bwd(g_cur, pidx, y, bn, bnm.weight, dgamma=grads[bnm.weight], dbeta=grads[bnm.bias],
-                                     acc_param=acc, training=training)
-                if dwst is None:
-                    dwst = torch.empty((64, 7, 8, 4), device=dy.device, dtype=dy.dtype)
-                    ops.stem_wgrad(p, dy, dwst, False)
-                else:
-                    ops.stem_wgrad(p, dy, dwst, True)
-                g_cur = None
-            else:  # pragma: no cover
-                raise RuntimeError(kind)
+            with ops.level_batch() as lb:
+                for at in range(steps - 1, -1, -1):
+                    for idx in range(nl - 1, -1, -1):
+                        lb.level(idx)
+                        lt = ltapes[idx]
+                        item = lt[at]
+                        kind = item[0]
+                        g_cur, cur_sums = g_curs[idx], sums_l[idx]
+                        if kind == "skip":
+                            _, lvl, x, bott = item
+                            gs = g_skip[lvl]
+                            wgrad(bott, x, gs, 1, 0)
+                            # the skip projection's data gradient is the LAST writer of the gradient of this layer's output
+                            cb = consumer_bnb(lt, at - 1)
+                            if g_cur is None:
+                                r = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, bnb=cb)
+                            else:
+                                r = ops.conv_dgrad(gs, wp(bott), x.shape[1:3], 1, 0, out=g_cur, accumulate=True, bnb=cb)
+                            g_cur, cur_sums = r if cb is not None else (r, None)
+                        elif kind == "block":
+                            _, blk, x, y1, bn1, z1, y2, bn2, yd, bnd, out = item
+                            s = blk.stride
+                            dy2, gm = bn_bwd(blk.bn2, g_cur, y2, bn2, masksrc=out, want_gm=True, sums=cur_sums)
+                            cur_sums = None
+                            if training:       # activation-checkpoint recompute side effect (SURVEY.md N3)
+                                ops.bn_ema_again(bn2, blk.bn2.running_mean, blk.bn2.running_var,
+                                                 y2.numel() // y2.shape[-1], momentum=blk.bn2.momentum)
+                                self._nbt.append(blk.bn2)
+                            wgrad(blk.conv2, z1, dy2, 1, 1, pro_of(z1, y1, bn1))
+                            g_z1, s1 = ops.conv_dgrad(dy2, wp(blk.conv2), z1.shape[1:3], 1, 1, bnb=(y1, None, bn1, True))
+                            dy1, _ = bn_bwd(blk.bn1, g_z1, y1, bn1, relu=True, sums=s1)
+                            if training:
+                                ops.bn_ema_again(bn1, blk.bn1.running_mean, blk.bn1.running_var,
+                                                 y1.numel() // y1.shape[-1], momentum=blk.bn1.momentum)
+                                self._nbt.append(blk.bn1)
+                            wgrad(blk.conv1, x, dy1, s, 1)
+                            if blk.downsample is not None:
+                                dyd, _ = bn_bwd(blk.downsample[1], gm, yd, bnd)
+                                wgrad(blk.downsample[0], x, dyd, s, 0)
+                                g_in = ops.conv_dgrad(dyd, wp(blk.downsample[0]), x.shape[1:3], s, 0)
+                            else:
+                                g_in = gm
+                            # conv1's data gradient is the last writer of this block's input gradient unless a skip
+                            # projection follows (first block of a layer: the next tape item is then "skip", not "block")
+                            cb = consumer_bnb(lt, at - 1)
+                            r = ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1, out=g_in, accumulate=True, bnb=cb)
+                            g_cur, cur_sums = r if cb is not None else (r, None)
+                        elif kind == "stem":
+                            _, _, p, y, bn, pidx, bnm = item
+                            acc = bnm.weight in grads
+                            if not acc:
+                                grads[bnm.weight] = self._galloc(bnm.weight)
+                                grads[bnm.bias] = self._galloc(bnm.bias)
+                            dy = ops.bn_pool_bwd(g_cur, pidx, y, bn, bnm.weight, dgamma=grads[bnm.weight],
+                                                 dbeta=grads[bnm.bias], acc_param=acc, training=training)
+                            if dwst is None:
+                                dwst = torch.empty((64, 7, 8, 4), device=dy.device, dtype=dy.dtype)
+                                ops.stem_wgrad(p, dy, dwst, False)
+                            else:
+                                ops.stem_wgrad(p, dy, dwst, True)
+                            g_cur = None
+                        else:  # pragma: no cover
+                            raise RuntimeError(kind)
+                        g_curs[idx], sums_l[idx] = g_cur, cur_sums
+                    lb.flush()
         if dwst is not None:
             grads[self.fe.conv1.weight] = ops.unpack_stem_weight(dwst, self.fe.conv1.weight,
                                                                  out=self._galloc(self.fe.conv1.weight))

@@ -35,19 +35,179 @@ def _stream():
 
 
 def _p(t: Optional[torch.Tensor]):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    if _batch is not None:
+        _batch.keep.append(t)          # a recorded launch reads / writes it later: its memory must not be recycled before
+    return C.c_void_p(t.data_ptr())
 
 
 _fn_cache = {}
 
 
-def _call(name: str, *args):
+def _call_now(name: str, *args):
     fn = _fn_cache.get(name)
     if fn is None:
         fn = _fn_cache[name] = getattr(_lib.load(), name)
     rc = fn(*args)
     if rc != 0:
         _lib.check(rc, name)
+
+
+def _call(name: str, *args):
+    if _batch is None:
+        _call_now(name, *args)
+    else:
+        _batch.record(name, args)
+
+
+# --------------------------------------------------------------------------- #
+# level batching: the pyramid levels of one layer as ONE launch per convolution
+# --------------------------------------------------------------------------- #
+# The three pyramid levels apply the same modules to maps of different size (network/backbone/resnet_pyramid.py:318-341).
+# Inside ``with level_batch() as lb`` the model runs a block for level 0, 1, 2 in turn (lb.level(i) before each) and then
+# lb.flush(): launches are RECORDED per level and emitted as a merge of the per-level sequences that keeps every level's
+# own order, in which the convolution launches standing at the head of several levels go out through the *_multi entries
+# (one grid, bitwise the per-level results: include/dcs_hip.h).  Launches of different levels that update the same
+# memory (running statistics, the shared weight / BatchNorm parameter gradients) keep their recorded order.
+_BATCHABLE = {"dcs_conv_gather_x3": ("dcs_conv_gather_x3_multi", _lib.DcsGatherLaunch),
+              "dcs_conv3x3_x3w": ("dcs_conv3x3_x3w_multi", _lib.DcsGatherLaunch),
+              "dcs_conv_wgrad_x3": ("dcs_conv_wgrad_x3_multi", _lib.DcsWgradLaunch)}
+# entry -> index of the argument that names memory shared between the levels (None argument: nothing shared)
+_ORDER_KEY_ARG = {"dcs_reduce_slab": 1, "dcs_bn_finalize": 3, "dcs_bn_ema_again": 1, "dcs_bn_bwd_apply": 8,
+                  "dcs_bn_pool_bwd_apply": 7}
+_batch = None
+launch_counts = {"single": 0, "multi": 0, "merged": 0}      # convolution launches emitted by level batches (diagnostics)
+
+
+def _ptr(a):
+    return a.value if isinstance(a, C.c_void_p) else a
+
+
+def _gather_struct(a, x3w):
+    if x3w:      # dcs_conv3x3_x3w(src, wfrag, bias, dst, geom, accumulate, stats, pro, bn_y, bn_mask, bn, relu, stream)
+        src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, _ = a
+        ns, slab = 1, 0
+    else:        # dcs_conv_gather_x3(..., relu, nsplit, slab_stride, stream)
+        src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, ns, slab, _ = a
+    return _lib.DcsGatherLaunch(_ptr(src), _ptr(w), _ptr(bias), _ptr(dst), C.pointer(g), _ptr(stats), _ptr(pro), _ptr(yb),
+                                _ptr(mb), _ptr(bnr), slab, acc, relu, ns)
+
+
+def _wgrad_struct(a):
+    src, dy, slab, g, dcs, split0, ns, pro, _ = a      # dcs_conv_wgrad_x3(src, dy, slab, geom, dy_cstride, split0, nsplit, pro, stream)
+    return _lib.DcsWgradLaunch(_ptr(src), _ptr(dy), _ptr(slab), C.pointer(g), _ptr(pro), dcs, split0, ns)
+
+
+class _LevelBatch:
+    def __init__(self):
+        self.seqs: List[list] = []
+        self.cur = 0
+        self.keep: list = []
+        self.keyq = {}
+        self.n = 0
+
+    def record(self, name, args):
+        while len(self.seqs) <= self.cur:
+            self.seqs.append([])
+        key = None
+        ka = _ORDER_KEY_ARG.get(name)
+        if ka is not None and args[ka] is not None:
+            key = (name, _ptr(args[ka]))
+            self.keyq.setdefault(key, []).append(self.n)
+        self.seqs[self.cur].append((name, args, key, self.n))
+        self.n += 1
+
+    def emit(self):
+        seqs = [q for q in self.seqs if q]
+        at = [0] * len(seqs)
+        kpos = {k: 0 for k in self.keyq}
+        left = sum(len(q) for q in seqs)
+        while left:
+            progress = False
+            moved = True
+            while moved:               # every level up to its next convolution (until nothing moves: a level may wait for
+                moved = False          # another level's earlier update of shared memory)
+                for L, q in enumerate(seqs):
+                    while at[L] < len(q) and q[at[L]][0] not in _BATCHABLE:
+                        name, args, key, cid = q[at[L]]
+                        if key is not None:
+                            if self.keyq[key][kpos[key]] != cid:
+                                break                  # an earlier update of the same memory by another level comes first
+                            kpos[key] += 1
+                        if name == "<py>":
+                            args()
+                        else:
+                            _call_now(name, *args)
+                        at[L] += 1
+                        left -= 1
+                        moved = progress = True
+            heads = [L for L, q in enumerate(seqs) if at[L] < len(q) and q[at[L]][0] in _BATCHABLE]
+            if heads:
+                names = [seqs[L][at[L]][0] for L in heads]
+                name = max(names, key=names.count)              # the entry most levels are waiting at (ties: the first)
+                grp = [L for L in heads if seqs[L][at[L]][0] == name][:_lib.MULTI_MAX]
+                calls = [seqs[L][at[L]][1] for L in grp]
+                if len(grp) == 1:
+                    _call_now(name, *calls[0])
+                    launch_counts["single"] += 1
+                else:
+                    multi, struct = _BATCHABLE[name]
+                    if struct is _lib.DcsWgradLaunch:
+                        arr = (struct * len(grp))(*[_wgrad_struct(a) for a in calls])
+                    else:
+                        arr = (struct * len(grp))(*[_gather_struct(a, name == "dcs_conv3x3_x3w") for a in calls])
+                    _call_now(multi, arr, len(grp), calls[0][-1])
+                    launch_counts["multi"] += 1
+                    launch_counts["merged"] += len(grp)
+                for L in grp:
+                    at[L] += 1
+                left -= len(grp)
+                progress = True
+            if not progress:                                  # cannot happen (see the ordering argument in DESIGN.md)
+                raise RuntimeError("level batch: no launch is ready")
+
+
+class level_batch:
+    """Context manager, see above.  DCS_LEVEL_BATCH=0 (or a nested use) turns it into a no-op: every launch then goes out
+    at once, level after level."""
+
+    def __enter__(self):
+        global _batch
+        self.own = _batch is None and os.environ.get("DCS_LEVEL_BATCH", "1") != "0"
+        if self.own:
+            _batch = _LevelBatch()
+        return self
+
+    def level(self, i: int):
+        if self.own:
+            _batch.cur = i
+
+    def flush(self):
+        global _batch
+        if not self.own or _batch is None:
+            return
+        b, _batch = _batch, None                 # emission itself launches at once
+        try:
+            b.emit()
+        finally:
+            _batch = _LevelBatch()
+
+    def __exit__(self, et, ev, tb):
+        global _batch
+        if self.own:
+            b, _batch = _batch, None
+            if et is None:
+                b.emit()
+        return False
+
+
+def _defer(fn):
+    """A torch operation on data that recorded launches produce or consume: runs in its place of the level's sequence."""
+    if _batch is None:
+        fn()
+    else:
+        _batch.record("<py>", fn)
 
 
 def _req(t: torch.Tensor, dtype=_F32):
@@ -243,7 +403,7 @@ def split_weight(wk):
     rows = wk.shape[0]
     ws = wk.numel() // rows
     out = torch.empty((rows, ws * 3 // 2), device=wk.device, dtype=_F32)
-    _call("dcs_split_weight", _p(wk), _p(out), rows, ws, _stream())
+    _call_now("dcs_split_weight", _p(wk), _p(out), rows, ws, _stream())
     if len(_split_cache) >= 1024:            # callers that never run a model forward (micro-benchmarks, tests)
         _split_cache.clear()
     _split_cache[key] = (wk, out)
@@ -261,7 +421,7 @@ def split_weight_frag(wk):
     ws = wk.numel() // rows
     J = -(-rows // 32)
     out = torch.empty((2 * (ws // 16) * J * 3 * 256,), device=wk.device, dtype=_F32)
-    _call("dcs_split_weight_frag", _p(wk), _p(out), rows, ws, _stream())
+    _call_now("dcs_split_weight_frag", _p(wk), _p(out), rows, ws, _stream())
     if len(_split_cache) >= 1024:
         _split_cache.clear()
     _split_cache[key] = (wk, out)
@@ -291,10 +451,10 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
     """One launch of the gather kernel family.  bnb = (y, mask, bn record, relu) or None."""
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
     if ns == 1 and x3_ok(g) and x3w_ok(g):
-        _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats),
+        _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
               _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _stream())
     elif x3_ok(g):
-        _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats),
+        _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
               _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _stream())
     elif bnb is not None:
         assert pro is None and ns == 1
@@ -363,7 +523,7 @@ def pack_dgrad_weight(w, koff=0, kw=None):
     Cout, Ktot, R, S = w.shape
     kw = kw or Ktot
     o = torch.empty((kw, R, S, Cout), device=w.device, dtype=_F32)
-    _call("dcs_pack_dgrad_weight", _p(krsc(w)), _p(o), Cout, R, S, kw, Ktot, koff, _stream())
+    _call_now("dcs_pack_dgrad_weight", _p(krsc(w)), _p(o), Cout, R, S, kw, Ktot, koff, _stream())
     return o
 
 
@@ -383,7 +543,7 @@ def conv_dgrad(dy, wp, in_hw, stride, pad, out=None, accumulate=False, src_cs=No
         accumulate = False
         out = (torch.zeros if any(g is None for g in gs) else torch.empty)((N, IH, IW, Cin), device=dy.device, dtype=_F32)
     elif not accumulate and any(g is None for g in gs):
-        out.zero_()
+        _defer(out.zero_)
     cs = dy.shape[3]
     fuse = bnb is not None and all(g is not None for g in gs) and out.is_contiguous() and Cin % 4 == 0
     part = None
@@ -465,7 +625,7 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
         x3 = M >= 64 * ns
     if x3:
         slab = torch.empty((ns, n), device=x.device, dtype=_F32)
-        _call("dcs_conv_wgrad_x3", _p(x), _p(dy), _p(slab), C.byref(g), dy.shape[3], 0, ns, _p(pro), _stream())
+        _call("dcs_conv_wgrad_x3", _p(x), _p(dy), _p(slab), g, dy.shape[3], 0, ns, _p(pro), _stream())
     else:
         if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 32 == 0:
             tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
@@ -490,7 +650,7 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
 
 def pack_stem_weight(w):
     o = torch.empty((w.shape[0], 7, 8, 4), device=w.device, dtype=_F32)
-    _call("dcs_pack_stem_weight", _p(krsc(w)), _p(o), w.shape[0], 0, _stream())
+    _call_now("dcs_pack_stem_weight", _p(krsc(w)), _p(o), w.shape[0], 0, _stream())
     return o
 
 
@@ -524,7 +684,7 @@ def stem_wgrad(p, dy, dwp, accumulate):
         ns = max(2, min(512, M // 64))
         ns += ns & 1
         slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
-        _call("dcs_conv_wgrad_x3", _p(p), _p(dy), _p(slab), C.byref(g), 64, 0, ns, None, _stream())
+        _call("dcs_conv_wgrad_x3", _p(p), _p(dy), _p(slab), g, 64, 0, ns, None, _stream())
         _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, 0, 0, _stream())
         return
     ns = max(1, min(512, M // 64)) if g.DW % 32 == 0 else _nsplit(7, M)   # seven-row stem kernel: one block per split

@@ -127,12 +127,37 @@ int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, floa
                     int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
                     const float* bn, int relu, void* stream);
 
+/* ---- level batching: up to DCS_MULTI_MAX launches of the entries above as ONE grid ---------------------------------------
+ * The three pyramid levels of a layer share every weight (network/backbone/resnet_pyramid.py:318-341: the same modules are
+ * applied to the image at scales 1, 1/2, 1/4) and therefore run the same kernel on maps of different extent.  A multi
+ * entry takes the argument lists of n single launches (one struct each, fields = the arguments of the single entry),
+ * validates every one exactly as the single entry would (nothing is launched unless all are valid; the first failing
+ * code is returned) and launches those that select the same kernel as one grid whose block ranges are assigned to the
+ * sub-launches; sub-launches that select different kernels go out separately.  A block executes the code of the single
+ * launch with its sub-launch's arguments, so results are BITWISE those of n single launches in any order; the
+ * sub-launches must not write overlapping memory (the levels' tensors never do). */
+#define DCS_MULTI_MAX 3
+typedef struct DcsGatherLaunch {
+  const float* src; const void* wgt; const float* bias; float* dst; const DcsConvGeom* geom;
+  float* stats; const float* pro; const float* bn_y; const float* bn_mask; const float* bn;
+  int64_t slab_stride;
+  int32_t accumulate, relu, nsplit;
+} DcsGatherLaunch;
+int dcs_conv_gather_x3_multi(const DcsGatherLaunch* launches, int n, void* stream);   /* n x dcs_conv_gather_x3 */
+int dcs_conv3x3_x3w_multi(const DcsGatherLaunch* launches, int n, void* stream);      /* n x dcs_conv3x3_x3w (nsplit 1) */
+
 /* dcs_conv_wgrad / dcs_conv_wgrad_pro (pro nullable) on the bf16 matrix cores, operands as three bf16 pieces; slabs of
  * odd split index carry the hardware's rounding bias with the opposite sign, so an EVEN nsplit cancels it in
  * dcs_reduce_slab.  Cout % 4 == 0; the stem in its seven-tap form with TX % 16 == 0, Cout 64, wstride 224, no prologue
  * (else DCS_E_UNSUPPORTED). */
 int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
                       int split0, int nsplit, const float* pro, void* stream);
+typedef struct DcsWgradLaunch {
+  const float* src; const float* dy; float* slab; const DcsConvGeom* geom; const float* pro;
+  int32_t dy_cstride, split0, nsplit;
+} DcsWgradLaunch;
+int dcs_conv_wgrad_x3_multi(const DcsWgradLaunch* launches, int n, void* stream);     /* n x dcs_conv_wgrad_x3, see above */
+
 
 /* dw[o(i)] = (accumulate ? dw[o(i)] : 0) + sum_s slab[s][i], fixed order (deterministic).
  * row_len == 0: o(i) = i.  row_len > 0: the slab holds compact rows of row_len floats that land at stride

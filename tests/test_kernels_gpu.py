@@ -793,3 +793,100 @@ def test_halo_kernel_with_weight_fragments_from_global_memory(ops, monkeypatch, 
     sums = torch.empty((2, Cin), device=DEV)
     _call("dcs_colsum_final", _p(partd), _p(sums), 1, tiles, Cin, 1.0, 0.0, _stream())
     assert torch.equal(d, d_ref) and torch.equal(sums, s_ref)
+
+
+LEVEL_MAPS = [
+    # N, (H, W) per level, Cin, Cout, k, stride
+    (2, [(32, 64), (16, 32), (8, 16)], 64, 64, 3, 1),       # halo kernel on the large level(s), per-tap on the small
+    (2, [(16, 64), (8, 32), (4, 16)], 128, 128, 3, 1),
+    (1, [(24, 40), (12, 20), (6, 10)], 64, 128, 3, 2),      # stride 2: four parity classes per level in the data gradient
+    (2, [(12, 20), (6, 10), (3, 5)], 256, 128, 1, 1),       # bottleneck projection
+    (1, [(6, 10), (3, 5), (2, 3)], 256, 512, 3, 2),         # K-split launches on the small levels
+]
+
+
+@pytest.mark.parametrize("N,maps,Cin,Cout,k,s", LEVEL_MAPS)
+def test_level_batched_launches_are_bitwise_the_per_level_launches(ops, monkeypatch, N, maps, Cin, Cout, k, s):
+    """ops.level_batch: the three pyramid levels of a layer through dcs_conv_gather_x3_multi / dcs_conv3x3_x3w_multi /
+    dcs_conv_wgrad_x3_multi (one grid for the levels that select the same kernel) against the same operations launched
+    level after level (DCS_LEVEL_BATCH=0): forward with BatchNorm statistics and prologue, data gradient with the
+    BatchNorm-backward sums, weight gradient accumulated over the levels into one dW -- all BITWISE equal."""
+    pad = k // 2
+    w = cl(rnd(Cout, Cin, k, k, seed=1, scale=0.05)).to(DEV)
+    xs = [rnd(N, h, wd, Cin, seed=10 + i).to(DEV) for i, (h, wd) in enumerate(maps)]
+    pros = [torch.stack([1 + 0.1 * rnd(Cin, seed=20 + i), 0.1 * rnd(Cin, seed=30 + i), torch.zeros(Cin), torch.ones(Cin)]).to(DEV)
+            for i in range(len(maps))]
+
+    def run():
+        out = []
+        wp = ops.pack_dgrad_weight(w)
+        dw = torch.empty_like(w)
+        ys = [None] * len(xs)
+        with ops.level_batch() as lb:
+            for i, x in enumerate(xs):
+                lb.level(i)
+                y, st = ops.conv_fwd(x, w, s, pad, want_stats=True, pro=pros[i] if ops.pro_ok(Cin) else None)
+                ys[i] = y
+                out += [y, st]
+            lb.flush()
+            for i in reversed(range(len(xs))):
+                lb.level(i)
+                dy = ys[i] * 0.5 + 0.25
+                bn = torch.stack([torch.ones(Cin), torch.zeros(Cin), torch.zeros(Cin), torch.ones(Cin)]).to(DEV)
+                gx, sums = ops.conv_dgrad(dy, wp, xs[i].shape[1:3], s, pad, bnb=(xs[i], None, bn, True))
+                ops.conv_wgrad(xs[i], dy, dw, s, pad, i != len(xs) - 1, pro=pros[i] if ops.pro_ok(Cin) else None)
+                out += [gx] + ([sums] if sums is not None else [])
+            lb.flush()
+        out.append(dw)
+        torch.cuda.synchronize()
+        return [t.clone() for t in out]
+
+    monkeypatch.setenv("DCS_LEVEL_BATCH", "0")
+    before = dict(ops.launch_counts)
+    ref = run()
+    assert ops.launch_counts == before                      # nothing went through a batch
+    monkeypatch.setenv("DCS_LEVEL_BATCH", "1")
+    got = run()
+    assert ops.launch_counts["multi"] > before["multi"], ops.launch_counts
+    assert len(ref) == len(got)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    # and the per-level results themselves are right (forward of level 0 against the CPU statement)
+    y0 = E.conv_fwd(xs[0].cpu(), w.cpu(), s, pad, pro=pros[0].cpu() if ops.pro_ok(Cin) else None)
+    close(got[0], y0, 2e-5, "level 0 forward")
+
+
+def test_level_batched_stem_is_bitwise_the_per_level_stem(ops, monkeypatch):
+    """The 7x7 stem of the three pyramid levels and its weight gradient through the multi entries."""
+    img = (rnd(2, 3, 128, 256, seed=3) * 40 + 100).to(DEV)
+    w = cl(rnd(64, 3, 7, 7, seed=4, scale=0.05)).to(DEV)
+    mean = torch.tensor([73.15, 82.90, 72.3], device=DEV)
+    std = torch.tensor([47.67, 48.49, 47.73], device=DEV)
+
+    def run():
+        pyr = ops.normalize_pyramid(img, mean, std)
+        wst = ops.pack_stem_weight(w)
+        dwst = torch.empty((64, 7, 8, 4), device=DEV)
+        out, ys = [], []
+        with ops.level_batch() as lb:
+            for i, p in enumerate(pyr):
+                lb.level(i)
+                y, st = ops.stem_conv(p, wst, want_stats=True)
+                ys.append(y)
+                out += [y, st]
+            lb.flush()
+            for i in reversed(range(3)):
+                lb.level(i)
+                ops.stem_wgrad(pyr[i], ys[i] * 0.5 + 0.1, dwst, i != 2)
+            lb.flush()
+        torch.cuda.synchronize()
+        return [t.clone() for t in out + [dwst]]
+
+    monkeypatch.setenv("DCS_LEVEL_BATCH", "0")
+    ref = run()
+    monkeypatch.setenv("DCS_LEVEL_BATCH", "1")
+    before = ops.launch_counts["multi"]
+    got = run()
+    assert ops.launch_counts["multi"] >= before + 2
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
