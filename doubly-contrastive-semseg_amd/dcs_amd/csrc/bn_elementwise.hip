@@ -97,6 +97,9 @@ void colsum_final_kernel(const float* __restrict__ partial, float* __restrict__ 
     double s0 = 0.0, s1 = 0.0;
     if (c < C) {
       const float* p = partial + (long long)b * groups * ld;
+      // the adds keep their order (bitwise the rolled loop); unrolling only puts 16 independent loads in flight per
+      // trip -- with 2048 row tiles this is a 256-trip latency chain on a handful of blocks
+#pragma unroll 8
       for (int gi = gl2; gi < groups; gi += 8) { s0 += (double)p[(long long)gi * ld + c]; s1 += (double)p[(long long)gi * ld + C + c]; }
     }
     double (*sm2)[32][2] = reinterpret_cast<double (*)[32][2]>(&sm[0][0][0]);

@@ -171,3 +171,18 @@ def test_second_backward_accumulates_on_the_flat_gradient_path(emu):
     run()
     for p, g1 in zip(params, once):
         assert torch.equal(p.grad, g1) and p.grad.data_ptr() == ts.flat.grad_view[p].data_ptr()
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 1000, 4097, 70000, 131072])
+def test_sampler_randperm_dtype_does_not_change_the_reference_stream(n):
+    """The sampler's host plan draws torch.randperm(n, dtype=int32) where the reference draws torch.randperm(n)
+    (utils/loss.py:314-325): same permutation, same generator state afterwards (the CPU generator is consumed per
+    element whatever the output type), so every later draw of the step -- and of the run -- is the reference's."""
+    torch.manual_seed(1234 + n)
+    a = torch.randperm(n)
+    sa = torch.get_rng_state().clone()
+    torch.manual_seed(1234 + n)
+    b = torch.randperm(n, dtype=torch.int32)
+    sb = torch.get_rng_state().clone()
+    assert torch.equal(a, b.long())
+    assert torch.equal(sa, sb)
