@@ -81,6 +81,7 @@ class ConvProfiler:
 
     def __init__(self, ops):
         self.ops, self.records, self.enabled = ops, [], False
+        self.event_host_s = 0.0
         self._orig = ops._call_now
 
         def cost(g):
@@ -104,10 +105,14 @@ class ConvProfiler:
                 flops = sum(cost(g)[0] for g in geoms)
                 abytes = sum(cost(g)[1] for g in geoms)
                 g = geoms[0]
+                th = time.perf_counter()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
+                self.event_host_s += time.perf_counter() - th
                 self._orig(name, *args)
+                th = time.perf_counter()
                 e1.record()
+                self.event_host_s += time.perf_counter() - th
                 kind = "dcs_conv_wgrad" if base.startswith("dcs_conv_wgrad") else "dcs_conv_gather"
                 fused = base.rsplit("_", 1)[1] if base.endswith(("_pro", "_bnbwd", "_x3", "_x3w")) else ""
                 if len(geoms) > 1:
@@ -308,9 +313,18 @@ def main():
         s0 = dict(left=left0, label=labels.clone(), weather=weather, label_distance_weight=ldw)
         return stepper.step((s0, dict(left=left1)) if two else s0)
 
+    # the first use of several hundred HIP events costs ~0.1 s of host time once: pay it here, not in a step
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(1024)]
+    for e in evs:
+        e.record()
+    torch.cuda.synchronize()
+    del evs
+    out = None
     for i in range(args.warmup):
-        prof.enabled = i == args.warmup - 1      # last warm-up step with the event profiler on (first use of several
-        one_step()                               # hundred HIP events costs ~0.1 s of host time once), then discarded
+        # `out` keeps the outputs of the previous step alive while the next one runs, exactly as in the timed loop below:
+        # the allocator then reaches its steady-state footprint here (dropping the result at once left a 4 GiB segment to
+        # be malloc'ed in the second TIMED step: 0-35 ms, measured)
+        out = one_step()
     prof.enabled = False
     prof.records.clear()
     # Python's cyclic collector: a generation-2 pass over the heap that `import torch` leaves behind costs ~100 ms of
@@ -326,9 +340,19 @@ def main():
     t0 = time.perf_counter()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     marks[0].record()
+    segs = []
     for i in range(args.steps):
+        th_ = time.perf_counter()
         out = one_step()
         marks[i + 1].record()
+        segs.append(torch.cuda.memory_stats(dev)["segment.all.allocated"])      # host-side counter: no sync
+        if os.environ.get("DCS_BENCH_DEBUG"):
+            st_ = torch.cuda.memory_stats(dev)
+            print("[debug] step %d: host %.1f ms (events %.1f ms) segments %d reserved %.2f GiB allocated(now) %.2f GiB gc %s" % (
+                i, (time.perf_counter() - th_) * 1e3, prof.event_host_s * 1e3, st_["segment.all.allocated"],
+                st_["reserved_bytes.all.current"] / 2 ** 30,
+                st_["allocated_bytes.all.current"] / 2 ** 30, [g["collections"] for g in gc.get_stats()]), file=sys.stderr)
+            prof.event_host_s = 0.0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -343,6 +367,11 @@ def main():
     if rank == 0:
         print("[bench] per-step GPU ms: " + " ".join(f"{marks[i].elapsed_time(marks[i + 1]):.1f}" for i in range(args.steps)),
               file=sys.stderr, flush=True)
+        st = torch.cuda.memory_stats(dev)
+        print("[bench] HBM: peak allocated %.1f GiB, peak reserved %.1f GiB, allocator retries %d, device mallocs %d" %
+              (st["allocated_bytes.all.peak"] / 2 ** 30, st["reserved_bytes.all.peak"] / 2 ** 30, st["num_alloc_retries"],
+               st["segment.all.allocated"]), file=sys.stderr, flush=True)
+        print("[bench] device mallocs after each timed step: " + " ".join(str(v) for v in segs), file=sys.stderr, flush=True)
         ms = dt / args.steps * 1e3
         value = b * world * args.steps / dt
         ps = prof.summary()
