@@ -86,6 +86,7 @@ SIGNATURES = {
     "dcs_scale_inplace": [_P, _L, _P, _P, _P],
     "dcs_anchor_keys": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],
     "dcs_anchor_select": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dcs_sampler_plan": [_P, _I, _I, _I, _I, _P, C.POINTER(C.c_int), _P, _P, _P, C.POINTER(C.c_int)],
     "dcs_gather_rows": [_P, _P, _P, _I, _I, _P],
     "dcs_scatter_add_rows": [_P, _P, _P, _I, _I, _P],
     "dcs_gather_rows_bilinear": [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

@@ -9,6 +9,8 @@ with identical RNG consumption.
 """
 from __future__ import annotations
 
+import os
+
 from abc import ABC
 from typing import List, Optional
 
@@ -471,15 +473,70 @@ class _PixelContrastLazyFn(torch.autograd.Function):
 
 
 def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):
-    """See _plan_anchor_requests.  torch.randperm on CPU is thread-count independent in its RESULT but, with
-    several intra-op threads, takes 30-150 ms per call for 32K < n < 100K (measured, torch 2.10) instead of
-    0.3 ms; the plan therefore runs with one intra-op thread."""
+    """Host half of utils/loss.py:264-337: see _plan_anchor_requests (the statement in torch) for the contract.
+
+    The plan runs in the library's host function dcs_sampler_plan on the state of torch's default CPU generator: the
+    reference's torch.randperm(n) calls shuffle 2.1 million elements per step at BASELINE config 3 to keep ~600 of them
+    (7 ms of host time, the device idle for ~4 ms of it); the first entries of a permutation need only its first draws,
+    the rest of the draws just advance the generator (csrc/sampler_host.cpp).  Same anchors, same generator state
+    afterwards (tests/test_host_logic_cpu.py).  DCS_SAMPLER_PLAN=torch, a non-default generator layout, or a case the
+    library leaves to the general path (n_view = 0, the reference's exception) take _plan_anchor_requests."""
+    if os.environ.get("DCS_SAMPLER_PLAN", "lib") != "torch" and max_views <= 8:
+        plan = _plan_in_library(counts, num_classes, max_samples, max_views)
+        if plan is not NotImplemented:
+            return plan
+    # torch.randperm on CPU is thread-count independent in its RESULT but, with several intra-op threads, takes
+    # 30-150 ms per call for 32K < n < 100K (measured, torch 2.10) instead of 0.3 ms: one intra-op thread
     nt = torch.get_num_threads()
     torch.set_num_threads(1)
     try:
         return _plan_anchor_requests(counts, num_classes, max_samples, max_views)
     finally:
         torch.set_num_threads(nt)
+
+
+_MT_N = 624
+_RNG_STATE_BYTES = 5056          # at::CPUGeneratorImplStateLegacy: seed u64, left i32, seeded i32, next u64, state u64[624], ...
+
+
+def _plan_in_library(counts, num_classes, max_samples, max_views):
+    import ctypes as C
+    import numpy as np
+    from . import lib as _lib
+    st = torch.get_rng_state()
+    if st.numel() != _RNG_STATE_BYTES:
+        return NotImplemented
+    raw = st.numpy()
+    left, seeded = (int(v) for v in raw[8:16].view(np.int32))
+    nxt = int(raw[16:24].view(np.uint64)[0])
+    words = raw[24:24 + 8 * _MT_N].view(np.uint64)
+    if not seeded or not (1 <= left <= _MT_N) or nxt > _MT_N:
+        return NotImplemented
+    key = words.astype(np.uint32)
+    pos0 = _MT_N if left == 1 else nxt                    # left == 1: the next draw regenerates the block
+    pos = C.c_int(pos0)
+    cnt = counts.to(torch.int64).contiguous().numpy()
+    B = cnt.shape[0]
+    req = np.empty((max_samples + max_views, 3), dtype=np.int32)
+    cls = np.empty((max_samples,), dtype=np.int32)
+    img = np.empty((max_samples,), dtype=np.int32)
+    n_view = C.c_int(0)
+    T = _lib.load().dcs_sampler_plan(cnt.ctypes.data, B, num_classes, max_samples, max_views, key.ctypes.data, C.byref(pos),
+                                     req.ctypes.data, cls.ctypes.data, img.ctypes.data, C.byref(n_view))
+    if T == -3:
+        return NotImplemented                             # generator untouched
+    if T < 0:
+        _lib.check(T, "dcs_sampler_plan")
+    if T == 0:
+        return None
+    # write the advanced generator back: after a draw, left + next = 625 (at::mt19937::operator())
+    if pos.value != pos0 or not np.array_equal(words, key):
+        words[:] = key
+        raw[8:12].view(np.int32)[0] = _MT_N + 1 - pos.value
+        raw[16:24].view(np.uint64)[0] = pos.value
+        torch.set_rng_state(st)
+    nv = n_view.value
+    return nv, T, req[:T * nv].tolist(), cls[:T].tolist(), img[:T].tolist()
 
 
 def _plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=1024, max_views=2):

@@ -280,6 +280,19 @@ int dcs_anchor_keys(const float* logits, int cs, int C, const int64_t* labels, i
  * (ascending index order = nonzero() order); -1 if absent.  hist as produced above. */
 int dcs_anchor_select(const uint8_t* key, const int32_t* hist, const int32_t* req, int32_t* out, int Q,
                       int N, int HW, int C, int chunk, void* stream);
+/* HOST function (no device work, no stream): the sampler's plan between dcs_anchor_keys and dcs_anchor_select -- which
+ * (image, class, hard|easy, rank) pixels become anchors (utils/loss.py:264-337).  counts [B][C][2] = pixels per (image,
+ * class, hard | easy) (the histogram of dcs_anchor_keys summed over chunks).  mt_state [624] / *mt_pos: the mt19937 of
+ * torch's default CPU generator (words, index of the next word; 624 = block exhausted), advanced in place exactly as the
+ * reference's torch.randperm(num_hard), torch.randperm(num_easy) per kept class advance it (a CPU randperm(n) is a forward
+ * Fisher-Yates shuffle on n - 1 32-bit draws; only the first n_view entries are ever used, the other draws are skipped by
+ * regenerating state blocks).  Returns T >= 0 = number of kept (image, class) pairs, with *n_view, req [T * n_view][3] =
+ * (image, 2 * class + is_easy, rank) in (t, view) order, cls [T], img [T] (capacity max_samples rows each); 0 = no class
+ * qualifies; DCS_E_UNSUPPORTED (generator untouched) where the reference's general path must decide (n_view = 0, or a class
+ * the reference raises on). */
+int dcs_sampler_plan(const int64_t* counts, int B, int C, int max_samples, int max_views, uint32_t* mt_state, int* mt_pos,
+                     int32_t* req, int32_t* cls, int32_t* img, int* n_view);
+
 /* X[a][0..C) = feat[(img[a]*HW + pix[a]) * C ..]  and the adjoint gfeat[...] += gX[a]. */
 int dcs_gather_rows(const float* feat, const int32_t* rowidx, float* X, int A, int C, void* stream);
 int dcs_scatter_add_rows(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, void* stream);

@@ -186,3 +186,65 @@ def test_sampler_randperm_dtype_does_not_change_the_reference_stream(n):
     sb = torch.get_rng_state().clone()
     assert torch.equal(a, b.long())
     assert torch.equal(sa, sb)
+
+
+def _random_counts(rng, B, C, big):
+    cnt = torch.zeros((B, C, 2), dtype=torch.int64)
+    for b in range(B):
+        for c in range(C):
+            kind = rng.integers(0, 6)
+            if kind == 0:
+                continue                                             # class absent
+            if kind == 1:
+                cnt[b, c, rng.integers(0, 2)] = int(rng.integers(1, 4))       # one, two or three pixels on one side
+            elif kind == 2:
+                cnt[b, c, 0] = int(rng.integers(0, 3)); cnt[b, c, 1] = int(rng.integers(0, 3))
+            else:
+                cnt[b, c, 0] = int(rng.integers(0, big)); cnt[b, c, 1] = int(rng.integers(0, big))
+    return cnt
+
+
+@pytest.mark.parametrize("seed,B,C,big,max_samples", [(0, 1, 5, 50, 1024), (1, 2, 19, 3000, 1024), (2, 4, 19, 140000, 1024),
+                                                      (3, 16, 19, 20000, 1024), (4, 3, 19, 700, 40), (5, 8, 19, 1300, 100),
+                                                      (6, 2, 7, 2000, 1024)])
+def test_library_sampler_plan_is_the_torch_plan(seed, B, C, big, max_samples):
+    """dcs_sampler_plan (csrc/sampler_host.cpp: sparse Fisher-Yates prefix + generator skip on the state of torch's CPU
+    generator) against the statement in torch (_plan_anchor_requests: torch.randperm per kept class, utils/loss.py:264-337):
+    same plan, and the SAME generator afterwards -- state bytes that matter and the next draws -- over absent classes,
+    classes with one to three pixels, empty hard or easy sides, 1.4e5-pixel classes and more classes than samples."""
+    from dcs_amd import losses
+    rng = np.random.default_rng(seed)
+    for rep in range(6):
+        cnt = _random_counts(rng, B, C, big)
+        torch.manual_seed(100 * seed + rep)
+        torch.rand(rep * 211)                                         # start somewhere inside a state block
+        s0 = torch.get_rng_state().clone()
+        try:
+            want = losses._plan_anchor_requests(cnt, C, max_samples, 2)
+            err = None
+        except Exception as e:                                        # the reference raises on some count patterns
+            want, err = None, e
+        after_want = torch.rand(5)
+        torch.set_rng_state(s0)
+        got = losses._plan_in_library(cnt, C, max_samples, 2)
+        if got is NotImplemented:
+            assert torch.equal(torch.get_rng_state(), s0)             # generator untouched: the general path takes over
+            n_classes = int(((cnt.sum(-1)) > 2).sum())
+            assert err is not None or (n_classes > 0 and max_samples // n_classes == 0), (seed, rep)
+            continue
+        assert err is None
+        assert got == want, (seed, rep)
+        assert torch.equal(torch.rand(5), after_want), (seed, rep)
+
+
+def test_library_sampler_plan_is_what_the_criterion_uses(monkeypatch):
+    from dcs_amd import losses
+    cnt = torch.tensor([[[5, 9], [0, 0], [1, 7]], [[3000, 2], [2, 1], [40, 50]]])
+    torch.manual_seed(3)
+    a = losses.plan_anchor_requests(cnt, 3, 1024, 2)
+    sa = torch.rand(3)
+    monkeypatch.setenv("DCS_SAMPLER_PLAN", "torch")
+    torch.manual_seed(3)
+    b = losses.plan_anchor_requests(cnt, 3, 1024, 2)
+    assert a == b and torch.equal(sa, torch.rand(3))
+    assert a[0] == 2 and a[1] == 5 and len(a[2]) == 10
