@@ -11,7 +11,9 @@ import json
 import sys
 from collections import defaultdict
 
-GROUPS = {"conv_gather": ("conv_gather_kernel", "conv_gather_x3_kernel", "conv3x3_x3_kernel", "conv3x3_x3w_kernel"), "conv_wgrad": ("conv_wgrad", "stem_wgrad_kernel")}
+# single launches and the level-batched *_multi launches of every family
+GROUPS = {"conv_gather": ("conv_gather_kernel", "conv_gather_x3_", "conv3x3_x3_kernel", "conv3x3_x3w_"),
+          "conv_wgrad": ("conv_wgrad", "stem_wgrad")}
 
 
 def group_of(name):
