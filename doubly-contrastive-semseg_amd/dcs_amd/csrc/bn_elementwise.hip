@@ -3,6 +3,7 @@
 // (fixed-order partial slabs, no float atomics).
 // Replaces nn.BatchNorm2d / nn.ReLU / residual add of network/backbone/resnet_pyramid.py:71-89
 // and network/utils.py:35-49 in the reference.
+#include <cstdlib>
 #include "dcs_common.h"
 
 namespace {
@@ -16,7 +17,7 @@ template <int MODE>
 __global__ __launch_bounds__(256)
 void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict__ y,
                            const float* __restrict__ masksrc, const float* __restrict__ bn,
-                           float* __restrict__ partial, long long rows, int Ctot, int cstride, int groups, int relu) {
+                           float* __restrict__ partial, long long rows, int Ctot, int cstride, int groups, int relu, int nt) {
   // Per-thread and per-block accumulation in DOUBLE: the BatchNorm-backward sums (sum g, sum g*xhat) cancel heavily
   // (their terms have mixed signs) and a sequential fp32 chain over a thread's few hundred rows loses what the
   // reference's CPU batch_norm_backward (double accumulators, at::acc_type<float, false>) keeps: measured 8-33x the
@@ -44,15 +45,15 @@ void colsum_partial_kernel(const float* __restrict__ x, const float* __restrict_
     }
     for (long long r = rbeg + rl; r < rend; r += RL) {
       const long long off = r * cstride + col4 * 4;
-      float4 v = ld4(xb + off);
+      float4 v = ld4s(xb + off, nt);
       if (MODE == 0) {
         const double d[4] = {(double)v.x, (double)v.y, (double)v.z, (double)v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) { a0[e] += d[e]; a1[e] = fma(d[e], d[e], a1[e]); }
       } else {
-        const float4 yy = ld4(y + cbase + off);
+        const float4 yy = ld4s(y + cbase + off, nt);
         if (masksrc) {
-          const float4 ms = ld4(masksrc + cbase + off);
+          const float4 ms = ld4s(masksrc + cbase + off, nt);
           v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f;
           v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
         } else if (relu) {
@@ -191,7 +192,7 @@ __global__ void bn_ema_again_kernel(const float* __restrict__ bn, float* __restr
 
 __global__ __launch_bounds__(256)
 void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bn, const float* __restrict__ r,
-                   const float* __restrict__ bn2, float* __restrict__ z, long long n4, int C, int relu) {
+                   const float* __restrict__ bn2, float* __restrict__ z, long long n4, int C, int relu, int nt) {
   const int C4 = C >> 2;
   // C/4 divides the block size for every BatchNorm width of the networks (64..2048 channels): a thread then keeps ONE
   // channel group for the whole grid-stride loop and its per-channel constants live in registers (7 fewer L1 loads per
@@ -205,21 +206,22 @@ void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bn, co
   if (hoist) tab((threadIdx.x % C4) * 4);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     if (!hoist) tab((int)(i % C4) * 4);
-    const float4 v = ld4(y + i * 4);
+    const float4 v = ld4s(y + i * 4, nt);
     float4 o;
     o.x = fmaf(v.x, sc.x, sh.x); o.y = fmaf(v.y, sc.y, sh.y); o.z = fmaf(v.z, sc.z, sh.z); o.w = fmaf(v.w, sc.w, sh.w);
     if (r) {
-      float4 q = ld4(r + i * 4);
+      float4 q = ld4s(r + i * 4, nt);
       if (bn2) {
         q.x = fmaf(q.x, s2.x, h2.x); q.y = fmaf(q.y, s2.y, h2.y); q.z = fmaf(q.z, s2.z, h2.z); q.w = fmaf(q.w, s2.w, h2.w);
       }
       o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-    st4(z + i * 4, o);
+    st4s(z + i * 4, o, nt);
   }
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256)
 void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ masksrc,
                          const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
@@ -250,10 +252,10 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
   if (hoist) tab((threadIdx.x % C4) * 4);
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
     if (!hoist) tab((int)(i % C4) * 4);
-    float4 v = ld4(g + i * 4);
-    const float4 yy = ld4(y + i * 4);
+    float4 v = ldx4<NT>(g + i * 4);
+    const float4 yy = ldx4<NT>(y + i * 4);
     if (masksrc) {
-      const float4 ms = ld4(masksrc + i * 4);
+      const float4 ms = ldx4<NT>(masksrc + i * 4);
       v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f; v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
     } else if (relu) {
       v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
@@ -262,7 +264,7 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
     if (gm_out) {
       float4 o = v;
       if (acc_gm) { const float4 p = ld4(gm_out + i * 4); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-      st4(gm_out + i * 4, o);
+      stx4<NT>(gm_out + i * 4, o);
     }
     if (dy) {
       float4 o;                                            // = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat))
@@ -271,7 +273,7 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
       o.z = gi.z * (v.z - t0.z - (yy.z - mu.z) * is.z * t1.z);
       o.w = gi.w * (v.w - t0.w - (yy.w - mu.w) * is.w * t1.w);
       if (acc_dy) { const float4 p = ld4(dy + i * 4); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
-      st4(dy + i * 4, o);
+      stx4<NT>(dy + i * 4, o);
     }
   }
 }
@@ -291,6 +293,16 @@ __global__ void scale_inplace_kernel(float* __restrict__ x, long long n, const f
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, long long n, float a) {
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
     y[i] = fmaf(a, x[i], y[i]);
+}
+// n % 4 == 0, 16-byte aligned operands
+__global__ __launch_bounds__(256)
+void axpy4_kernel(float* __restrict__ y, const float* __restrict__ x, long long n4, float a, int nt) {
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 u = ld4s(x + i * 4, nt);
+    float4 v = ld4s(y + i * 4, nt);
+    v.x = fmaf(a, u.x, v.x); v.y = fmaf(a, u.y, v.y); v.z = fmaf(a, u.z, v.z); v.w = fmaf(a, u.w, v.w);
+    st4s(y + i * 4, v, nt);
+  }
 }
 
 __global__ void add_rowvec_bcast_kernel(float* __restrict__ g, const float* __restrict__ v, long long HW, int C,
@@ -382,12 +394,13 @@ extern "C" int dcs_colsum_partial(const float* x, const float* y, const float* m
   const int C4 = Cb / 4, RL = 256 / C4;
   const size_t sh = (size_t)2 * RL * Cb * sizeof(double);
   dim3 grid((unsigned)groups, (unsigned)B, (unsigned)((C + 511) / 512));
+  const int nt = dcs_streams((long long)B * rows * cstride * 4) ? 1 : 0;
   if (mode == 0)
     hipLaunchKernelGGL(colsum_partial_kernel<0>, grid, dim3(256), sh, dcs_stream(stream), x, y, masksrc, bn, partial,
-                       (long long)rows, C, cstride, groups, relu);
+                       (long long)rows, C, cstride, groups, relu, nt);
   else
     hipLaunchKernelGGL(colsum_partial_kernel<1>, grid, dim3(256), sh, dcs_stream(stream), x, y, masksrc, bn, partial,
-                       (long long)rows, C, cstride, groups, relu);
+                       (long long)rows, C, cstride, groups, relu, nt);
   DCS_LAUNCH_RET();
 }
 
@@ -421,7 +434,8 @@ extern "C" int dcs_bn_act(const float* y, const float* bn, const float* r, const
                           int C, int relu, void* stream) {
   DCS_CHECK_ARG(y && bn && z && rows > 0 && C > 0 && (C & 3) == 0 && dcs_aligned16(y) && dcs_aligned16(z));
   const long long n4 = (long long)rows * (C / 4);
-  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), y, bn, r, bn2, z, n4, C, relu);
+  hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), y, bn, r, bn2, z, n4, C, relu,
+                     dcs_streams(n4 * 16) ? 1 : 0);
   DCS_LAUNCH_RET();
 }
 
@@ -433,8 +447,13 @@ extern "C" int dcs_bn_bwd_apply(const float* g, const float* y, const float* mas
   DCS_CHECK_ARG(!dy || (gamma && sums));
   DCS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || sums));
   const long long n4 = (long long)rows * (C / 4);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
-                     sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training);
+  const bool nt = dcs_streams(n4 * 16);               // >= 256 MiB per tensor: nothing to keep in the caches
+  if (nt)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
+                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
+                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training);
   DCS_LAUNCH_RET();
 }
 
@@ -446,7 +465,11 @@ extern "C" int dcs_scale_inplace(float* x, int64_t n, const float* a, const floa
 
 extern "C" int dcs_axpy(float* y, const float* x, int64_t n, float a, void* stream) {
   DCS_CHECK_ARG(x && y && n > 0);
-  hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), y, x, (long long)n, a);
+  if ((n & 3) == 0 && dcs_aligned16(x) && dcs_aligned16(y))
+    hipLaunchKernelGGL(axpy4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, dcs_stream(stream), y, x, (long long)n / 4, a,
+                       dcs_streams((long long)n * 4) ? 1 : 0);
+  else
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n)), dim3(256), 0, dcs_stream(stream), y, x, (long long)n, a);
   DCS_LAUNCH_RET();
 }
 

@@ -69,6 +69,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
   float* stg = smem + wid * (32 * EPL);
   float* st = smem + 4 * 32 * EPL;        // [WM][BN][2] statistics scratch
   const bool vec_ok = (dst_cstride & 3) == 0 && (reinterpret_cast<unsigned long long>(dst) & 15ull) == 0;
+  // accumulate: bit 0 = add to the destination, bit 1 = the destination (and the BatchNorm-backward operands beside it)
+  // is far larger than the caches: streaming accesses (dcs_common.h, ld4s / st4s)
+  const bool acc_dst = (accumulate & 1) != 0, nt = (accumulate & 2) != 0;
   float ssum[TN], ssq[TN];
 #pragma unroll
   for (int b = 0; b < TN; ++b) { ssum[b] = 0.f; ssq[b] = 0.f; }
@@ -110,13 +113,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
       float4 v = ld4(&stg[rl * EPL + c4 * 4]);
       float* q = dst + ro + colv;
       if (vec_ok && colv + 3 < Cout) {
-        if (accumulate) { const float4 o = ld4(q); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        *reinterpret_cast<float4*>(q) = v;
+        if (acc_dst) { const float4 o = ld4s(q, nt); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        st4s(q, v, nt);
         if (do_bnb) {
-          const float4 yy = ld4(bnb.y + ro + colv);
+          const float4 yy = ld4s(bnb.y + ro + colv, nt);
           float4 gm = v;
           if (bnb.mask) {
-            const float4 ms = ld4(bnb.mask + ro + colv);
+            const float4 ms = ld4s(bnb.mask + ro + colv, nt);
             gm.x = ms.x > 0.f ? gm.x : 0.f; gm.y = ms.y > 0.f ? gm.y : 0.f; gm.z = ms.z > 0.f ? gm.z : 0.f; gm.w = ms.w > 0.f ? gm.w : 0.f;
           } else if (bnb.relu) {
             gm.x = fmaf(yy.x, b_sc.x, b_sh.x) > 0.f ? gm.x : 0.f; gm.y = fmaf(yy.y, b_sc.y, b_sh.y) > 0.f ? gm.y : 0.f;
@@ -130,7 +133,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
         const float vv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-          if (colv + e < Cout) q[e] = accumulate ? q[e] + vv[e] : vv[e];
+          if (colv + e < Cout) q[e] = acc_dst ? q[e] + vv[e] : vv[e];
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");

@@ -1629,7 +1629,8 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
   if (nsplit > 1) cps += cps & 1;
   P.g = *geom;
   P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), a.bias, a.dst, a.stats, a.pro, bnb,
-                  (long long)a.slab_stride, a.accumulate, ntiles, cps, 0, 0u, 0, 0, 0};
+                  (long long)a.slab_stride, (a.accumulate ? 1 : 0) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), ntiles, cps,
+                  0, 0u, 0, 0, 0};
   P.nbx = (unsigned)blocks;
   P.nby = (unsigned)nsplit;
   // DCS_X3_HALO=0: never; =2: whenever the geometry allows (tests: small shapes); default: when there are enough tiles
@@ -1678,7 +1679,8 @@ int plan_x3w(const DcsGatherLaunch& a, GatherPlan& P) {
   const long long units = (long long)(geom->wstride >> 4) * J * 3 * 64;
   P.g = *geom;
   P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), a.bias, a.dst, a.stats, a.pro, bnb, 0ll,
-                  a.accumulate, ntiles, 0, J, (unsigned)(units * 16), 0, 0, 0};
+                  (a.accumulate ? 1 : 0) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), ntiles, 0, J,
+                  (unsigned)(units * 16), 0, 0, 0};
   P.kid = bn_ == 64 ? GK_X3W_64 : GK_X3W_128;
   P.nbx = (unsigned)((M / (bn_ == 64 ? 256 : 128)) * ntiles);
   P.nby = 1;

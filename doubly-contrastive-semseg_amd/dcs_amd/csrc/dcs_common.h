@@ -1,6 +1,7 @@
 // Shared device/host helpers for libdcs_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <stdint.h>
 #include "dcs_hip.h"
 
@@ -17,6 +18,38 @@ __device__ __forceinline__ int dcs_xcd_remap(int bid, int nwg) {
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
   const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return base + idx;
+}
+
+// Streaming (non-temporal) 16-byte accesses for tensors far larger than L2 + MALL: a single-pass kernel gains 5-29 % of
+// HBM bandwidth when its lines do not displace each other in the caches (tools/bn_nt_probe.py: BatchNorm-backward apply
+// 4.5-4.8 -> 5.6-5.8 TB/s).  NT as a template flag or as a wave-uniform runtime flag.
+typedef float dcs_f32x4 __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ldx4(const float* p) {
+  if constexpr (NT) {
+    const dcs_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const dcs_f32x4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+  } else {
+    return *reinterpret_cast<const float4*>(p);
+  }
+}
+template <bool NT>
+__device__ __forceinline__ void stx4(float* p, const float4 v) {
+  if constexpr (NT) {
+    const dcs_f32x4 w = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(w, reinterpret_cast<dcs_f32x4*>(p));
+  } else {
+    *reinterpret_cast<float4*>(p) = v;
+  }
+}
+__device__ __forceinline__ float4 ld4s(const float* p, const bool nt) { return nt ? ldx4<true>(p) : ldx4<false>(p); }
+__device__ __forceinline__ void st4s(float* p, const float4 v, const bool nt) {
+  if (nt) stx4<true>(p, v); else stx4<false>(p, v);
+}
+// does a tensor of this many bytes stream?  (DCS_BN_NT=0: never -- A/B switch)
+static inline bool dcs_streams(long long bytes) {
+  const char* e = getenv("DCS_BN_NT");
+  return bytes >= (256ll << 20) && !(e && e[0] == '0');
 }
 
 __device__ __forceinline__ float dcs_wave_sum(float v) {

@@ -57,7 +57,7 @@ __global__ void bicubic_down_kernel(const float* __restrict__ x0, float* __restr
 // ---- stem: maxpool 3x3/2 pad 1 over relu(y*scale+shift), argmax kept as 0..8 -------------------------
 __global__ __launch_bounds__(256)
 void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ bn, float* __restrict__ out,
-                            uint8_t* __restrict__ idx, int N, int H, int W, int OH, int OW, int C) {
+                            uint8_t* __restrict__ idx, int N, int H, int W, int OH, int OW, int C, int nt) {
   const int C4 = C >> 2;
   const long long total = (long long)N * OH * OW * C4;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -87,7 +87,7 @@ void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict
         if (z3 > best.w) { best.w = z3; b3 = k; }
       }
     }
-    st4(out + i * 4, best);
+    st4s(out + i * 4, best, nt);
     *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4((unsigned char)b0, (unsigned char)b1, (unsigned char)b2, (unsigned char)b3);
   }
 }
@@ -163,7 +163,7 @@ __device__ __forceinline__ void pool_quad_grad(const float* __restrict__ g, cons
 __global__ __launch_bounds__(256)
 void bn_pool_bwd_partial_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, const float* __restrict__ y,
                                 const float* __restrict__ bn, float* __restrict__ partial, int N, int H, int W, int OH,
-                                int OW, int C, int groups) {
+                                int OW, int C, int groups, int nt) {
   extern __shared__ __attribute__((aligned(16))) double smd[];   // [2][RL][C]; double: see colsum_partial_kernel
   const int C4 = C >> 2, RL = 256 / C4;
   const int tid = threadIdx.x, col4 = tid % C4, rl = tid / C4;
@@ -185,7 +185,7 @@ void bn_pool_bwd_partial_kernel(const float* __restrict__ g, const uint8_t* __re
     for (int p = 0; p < 4; ++p) {
       const int iy = 2 * qy + (p >> 1), ix = 2 * qx + (p & 1);
       if (iy >= H || ix >= W) continue;
-      const float4 yy = ld4(y + (((long long)n * H + iy) * W + ix) * C + c);
+      const float4 yy = ld4s(y + (((long long)n * H + iy) * W + ix) * C + c, nt);
       float4 v = gq[p];
       v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
       v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256)
 void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, const float* __restrict__ y,
                               const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
                               float* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int H,
-                              int W, int OH, int OW, int C, int acc_param, int training) {
+                              int W, int OH, int OW, int C, int acc_param, int training, int nt) {
   const int C4 = C >> 2;
   const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
   const long long total = (long long)N * QH * QW * C4;
@@ -239,7 +239,7 @@ void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __rest
       const int iy = 2 * qy + (p >> 1), ix = 2 * qx + (p & 1);
       if (iy >= H || ix >= W) continue;
       const long long off = (((long long)n * H + iy) * W + ix) * C + c;
-      const float4 yy = ld4(y + off);
+      const float4 yy = ld4s(y + off, nt);
       float4 v = gq[p];
       v.x = fmaf(yy.x, sc.x, sh.x) > 0.f ? v.x : 0.f; v.y = fmaf(yy.y, sc.y, sh.y) > 0.f ? v.y : 0.f;
       v.z = fmaf(yy.z, sc.z, sh.z) > 0.f ? v.z : 0.f; v.w = fmaf(yy.w, sc.w, sh.w) > 0.f ? v.w : 0.f;
@@ -248,7 +248,7 @@ void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __rest
       o.y = gw.y * is.y * (v.y - s0.y * inv - (yy.y - mu.y) * is.y * (s1.y * inv));
       o.z = gw.z * is.z * (v.z - s0.z * inv - (yy.z - mu.z) * is.z * (s1.z * inv));
       o.w = gw.w * is.w * (v.w - s0.w * inv - (yy.w - mu.w) * is.w * (s1.w * inv));
-      st4(dy + off, o);
+      st4s(dy + off, o, nt);
     }
   }
 }
@@ -275,7 +275,7 @@ __device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, 
 __global__ __launch_bounds__(256)
 void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ s0, const float* __restrict__ s1,
                          const float* __restrict__ s2, float* __restrict__ t, int N, int IH, int IW, int OH, int OW,
-                         int C) {
+                         int C, int nt) {
   const int C4 = C >> 2;
   const long long total = (long long)N * OH * OW * C4;
   const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
@@ -293,12 +293,12 @@ void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ 
     const float4 bot = f4axpy(lx.w1, v11, f4scale(lx.w0, v10));
     float4 r = f4axpy(ly.w1, bot, f4scale(ly.w0, top));
     if (s0) {
-      float4 sk = ld4(s0 + i * 4);          // python sum(): ((0 + s0) + s1) + s2, then x + skip
-      if (s1) sk = f4add(sk, ld4(s1 + i * 4));
-      if (s2) sk = f4add(sk, ld4(s2 + i * 4));
+      float4 sk = ld4s(s0 + i * 4, nt);     // python sum(): ((0 + s0) + s1) + s2, then x + skip
+      if (s1) sk = f4add(sk, ld4s(s1 + i * 4, nt));
+      if (s2) sk = f4add(sk, ld4s(s2 + i * 4, nt));
       r = f4add(r, sk);
     }
-    st4(t + i * 4, r);
+    st4s(t + i * 4, r, nt);
   }
 }
 
@@ -522,7 +522,7 @@ extern "C" int dcs_bn_relu_maxpool(const float* y, const float* bn, float* out, 
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * OH * OW * (C / 4);
   hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), y, bn, out, idx, N, H,
-                     W, OH, OW, C);
+                     W, OH, OW, C, dcs_streams(total * 16) ? 1 : 0);
   DCS_LAUNCH_RET();
 }
 
@@ -542,7 +542,7 @@ extern "C" int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const size_t sh = (size_t)2 * (256 / (C / 4)) * C * sizeof(double);
   hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3((unsigned)groups), dim3(256), sh, dcs_stream(stream), g, idx, y, bn,
-                     partial, N, H, W, OH, OW, C, groups);
+                     partial, N, H, W, OH, OW, C, groups, dcs_streams((long long)N * H * W * C * 4) ? 1 : 0);
   DCS_LAUNCH_RET();
 }
 
@@ -554,7 +554,8 @@ extern "C" int dcs_bn_pool_bwd_apply(const float* g, const uint8_t* idx, const f
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), g, idx, y, bn, gamma,
-                     sums, dy, dgamma, dbeta, N, H, W, OH, OW, C, acc_param, training);
+                     sums, dy, dgamma, dbeta, N, H, W, OH, OW, C, acc_param, training,
+                     dcs_streams((long long)N * H * W * C * 4) ? 1 : 0);
   DCS_LAUNCH_RET();
 }
 
@@ -564,7 +565,7 @@ extern "C" int dcs_upsample_add(const float* x, const float* s0, const float* s1
   DCS_CHECK_ARG(s0 || (!s1 && !s2));
   const long long total = (long long)N * OH * OW * (C / 4);
   hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), x, s0, s1, s2, t, N, IH,
-                     IW, OH, OW, C);
+                     IW, OH, OW, C, dcs_streams(total * 16) ? 1 : 0);
   DCS_LAUNCH_RET();
 }
 
