@@ -49,7 +49,9 @@ __device__ __forceinline__ void st4s(float* p, const float4 v, const bool nt) {
 // does a tensor of this many bytes stream?  (DCS_BN_NT=0: never -- A/B switch)
 static inline bool dcs_streams(long long bytes) {
   const char* e = getenv("DCS_BN_NT");
-  return bytes >= (256ll << 20) && !(e && e[0] == '0');
+  const char* m = getenv("DCS_NT_MIN_MB");          // threshold: C3 steps are flat (+-0.5 ms) between 64 and 512 MiB
+  const long long min_mb = m ? atoll(m) : 256;
+  return bytes >= (min_mb << 20) && !(e && e[0] == '0');
 }
 
 __device__ __forceinline__ float dcs_wave_sum(float v) {
