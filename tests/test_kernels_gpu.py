@@ -890,3 +890,55 @@ def test_level_batched_stem_is_bitwise_the_per_level_stem(ops, monkeypatch):
     assert ops.launch_counts["multi"] >= before + 2
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+def test_streaming_access_paths_are_bitwise_the_default_paths(ops, monkeypatch):
+    """Tensors of >= 256 MiB go through non-temporal loads / stores (dcs_common.h: dcs_streams) in the single-pass kernels
+    and in the convolution epilogue.  The arithmetic is the same, only the cache policy differs: with the threshold forced
+    to 0 (every tensor streams) each operation must return BITWISE what it returns with streaming off -- and the default
+    path is what all other tests hold against the CPU statements."""
+    N, H, W, C = 2, 24, 40, 64
+    x = rnd(N, H, W, C, seed=1).to(DEV)
+    g = rnd(N, H, W, C, seed=2).to(DEV)
+    r = rnd(N, H, W, C, seed=3).to(DEV)
+    w = cl(rnd(128, C, 3, 3, seed=4, scale=0.05)).to(DEV)
+    bn = torch.stack([1 + 0.1 * rnd(C, seed=5), 0.1 * rnd(C, seed=6), 0.1 * rnd(C, seed=7), 1 + 0.1 * rnd(C, seed=8).abs()]).to(DEV)
+    gamma = (1 + 0.1 * rnd(C, seed=9)).to(DEV)
+    low = rnd(N, H // 2, W // 2, C, seed=10).to(DEV)
+
+    def run():
+        out = []
+        y, st = ops.conv_fwd(x, w, 1, 1, want_stats=True, pro=bn)
+        out += [y, st]
+        wp = ops.pack_dgrad_weight(w)
+        gx, sums = ops.conv_dgrad(y, wp, (H, W), 1, 1, bnb=(x, r, bn, False))
+        out += [gx, sums]
+        acc = g.clone()
+        ops.conv_dgrad(y, wp, (H, W), 1, 1, out=acc, accumulate=True)
+        out.append(acc)
+        out.append(ops.bn_act(x, bn, r=r, bn2=bn, relu=True))
+        dy, gm = ops.bn_bwd(g, x, bn, gamma, masksrc=r, want_gm=True)
+        out += [dy, gm]
+        out.append(ops.bn_bwd(g, x, bn, gamma, relu=True)[0])
+        pooled, idx = ops.bn_relu_maxpool(x, bn)
+        out += [pooled, idx]
+        dg, db = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        out.append(ops.bn_pool_bwd(pooled * 0.5, idx, x, bn, gamma, dgamma=dg, dbeta=db))
+        out += [dg, db]
+        out.append(ops.upsample_add(low, [x, r], H, W))
+        out.append(ops.colsum(x.reshape(-1, C), moments=True))
+        a = x.clone()
+        ops.axpy(a, g, 0.5)
+        out.append(a)
+        torch.cuda.synchronize()
+        return [t.clone() for t in out if t is not None]
+
+    monkeypatch.setenv("DCS_KSPLIT", "0")          # keep the fused BatchNorm-backward epilogue on this small map
+    monkeypatch.setenv("DCS_BN_NT", "0")
+    ref = run()
+    monkeypatch.setenv("DCS_BN_NT", "1")
+    monkeypatch.setenv("DCS_NT_MIN_MB", "0")
+    got = run()
+    assert len(ref) == len(got) >= 17
+    for i, (a, b) in enumerate(zip(ref, got)):
+        assert torch.equal(a, b), i
