@@ -76,7 +76,7 @@ _BATCHABLE = {"dcs_conv_gather_x3": ("dcs_conv_gather_x3_multi", _lib.DcsGatherL
 # entry -> index of the argument that names memory shared between the levels (None argument: nothing shared)
 _ORDER_KEY_ARG = {"dcs_reduce_slab": 1, "dcs_bn_finalize": 3, "dcs_bn_ema_again": 1, "dcs_bn_bwd_apply": 8,
                   "dcs_bn_pool_bwd_apply": 7}
-_batch = None
+_batch = None          # the active recorder (one per process: the step runs on one host thread)
 launch_counts = {"single": 0, "multi": 0, "merged": 0}      # convolution launches emitted by level batches (diagnostics)
 
 
@@ -113,7 +113,7 @@ class _LevelBatch:
         key = None
         ka = _ORDER_KEY_ARG.get(name)
         if ka is not None and args[ka] is not None:
-            key = (name, _ptr(args[ka]))
+            key = _ptr(args[ka])            # the memory itself: different entries updating it are ordered too
             self.keyq.setdefault(key, []).append(self.n)
         self.seqs[self.cur].append((name, args, key, self.n))
         self.n += 1
