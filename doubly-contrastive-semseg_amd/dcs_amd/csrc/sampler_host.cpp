@@ -5,8 +5,8 @@
 // n - 1 draws of the 32-bit mt19937 (z_i = draw_i % (n - i), swap(r[i], r[i + z_i]), i = 0 .. n-2) -- checked against
 // torch.randperm for n up to 2 * 10^6 including the generator state afterwards (tests/test_host_logic_cpu.py).  So the first
 // k entries of the permutation need only the first k draws, and the remaining n - 1 - k draws only ADVANCE the generator.
-// At BASELINE config 3 a step shuffles 2.1 million elements to keep ~600 of them: 7 ms of host time in torch, of which the
-// device waits ~4 ms.  Here the kept entries come from a sparse Fisher-Yates prefix and the generator is advanced by
+// At BASELINE config 3 a step shuffles 2.1 million elements to keep ~600 of them: 6-7 ms of host time in torch, of which the
+// device waits ~4 ms (0.46 ms here).  Here the kept entries come from a sparse Fisher-Yates prefix and the generator is advanced by
 // regenerating its state blocks without producing (tempering, reducing, swapping) the skipped outputs.
 #include <cstdint>
 #include <cstring>

@@ -477,7 +477,7 @@ def plan_anchor_requests(counts: torch.Tensor, num_classes: int, max_samples=102
 
     The plan runs in the library's host function dcs_sampler_plan on the state of torch's default CPU generator: the
     reference's torch.randperm(n) calls shuffle 2.1 million elements per step at BASELINE config 3 to keep ~600 of them
-    (7 ms of host time, the device idle for ~4 ms of it); the first entries of a permutation need only its first draws,
+    (6-7 ms of host time, the device idle for ~4 ms of it); the first entries of a permutation need only its first draws,
     the rest of the draws just advance the generator (csrc/sampler_host.cpp).  Same anchors, same generator state
     afterwards (tests/test_host_logic_cpu.py).  DCS_SAMPLER_PLAN=torch, a non-default generator layout, or a case the
     library leaves to the general path (n_view = 0, the reference's exception) take _plan_anchor_requests."""
