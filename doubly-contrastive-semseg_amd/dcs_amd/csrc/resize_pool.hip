@@ -275,7 +275,13 @@ __device__ __forceinline__ void out_range(int i, float scale, int out, int& lo, 
 __global__ __launch_bounds__(256)
 void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ s0, const float* __restrict__ s1,
                          const float* __restrict__ s2, float* __restrict__ t, int N, int IH, int IW, int OH, int OW,
-                         int C, int nt) {
+                         int C, int nt, float* __restrict__ partial) {
+  // partial (nullable) [gridDim.x][2][C]: per-block sums / sums of squares of the values written -- the batch statistics
+  // of the BatchNorm that follows (network/utils.py:36-41 after :89-102) without a pass of their own.  Needs
+  // 256 % (C/4) == 0 (a thread keeps its channel group over the grid-stride loop); double accumulators like
+  // colsum_partial_kernel, rounded to fp32 once per block.
+  extern __shared__ __attribute__((aligned(16))) double smd_ua[];     // [2][RL][C] when partial
+  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
   const int C4 = C >> 2;
   const long long total = (long long)N * OH * OW * C4;
   const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
@@ -299,6 +305,26 @@ void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ 
       r = f4add(r, sk);
     }
     st4s(t + i * 4, r, nt);
+    if (partial) {
+      const double d[4] = {(double)r.x, (double)r.y, (double)r.z, (double)r.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a0[e] += d[e]; a1[e] = fma(d[e], d[e], a1[e]); }
+    }
+  }
+  if (partial) {
+    const int RL = 256 / C4, col4 = threadIdx.x % C4, rl = threadIdx.x / C4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      smd_ua[(0 * RL + rl) * C + col4 * 4 + e] = a0[e];
+      smd_ua[(1 * RL + rl) * C + col4 * 4 + e] = a1[e];
+    }
+    __syncthreads();
+    for (int u = threadIdx.x; u < 2 * C; u += 256) {
+      const int which = u / C, c = u - which * C;
+      double sum = 0.0;
+      for (int k = 0; k < RL; ++k) sum += smd_ua[(which * RL + k) * C + c];     // fixed order
+      partial[((long long)blockIdx.x * 2 + which) * C + c] = (float)sum;
+    }
   }
 }
 
@@ -565,7 +591,21 @@ extern "C" int dcs_upsample_add(const float* x, const float* s0, const float* s1
   DCS_CHECK_ARG(s0 || (!s1 && !s2));
   const long long total = (long long)N * OH * OW * (C / 4);
   hipLaunchKernelGGL(upsample_add_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), x, s0, s1, s2, t, N, IH,
-                     IW, OH, OW, C, dcs_streams(total * 16) ? 1 : 0);
+                     IW, OH, OW, C, dcs_streams(total * 16) ? 1 : 0, (float*)nullptr);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_upsample_add_stats(const float* x, const float* s0, const float* s1, const float* s2, float* t,
+                                      float* partial, int groups, int N, int IH, int IW, int OH, int OW, int C,
+                                      void* stream) {
+  DCS_CHECK_ARG(x && t && partial && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && (C & 3) == 0);
+  DCS_CHECK_ARG(s0 || (!s1 && !s2));
+  DCS_CHECK_ARG(C <= 1024 && 256 % (C / 4) == 0 && groups > 0 && groups <= 2048);
+  const long long total = (long long)N * OH * OW * (C / 4);
+  DCS_CHECK_ARG((long long)groups * 256 <= total + 255);          // every block owns at least one element: partial fully written
+  const size_t sh = (size_t)2 * (256 / (C / 4)) * C * sizeof(double);
+  hipLaunchKernelGGL(upsample_add_kernel, dim3((unsigned)groups), dim3(256), sh, dcs_stream(stream), x, s0, s1, s2, t, N, IH,
+                     IW, OH, OW, C, dcs_streams(total * 16) ? 1 : 0, partial);
   DCS_LAUNCH_RET();
 }
 

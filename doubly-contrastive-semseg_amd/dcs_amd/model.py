@@ -284,24 +284,33 @@ class SwiftNetEngine:
             tape.append(("levels", ltapes))
         skips = skips[::-1]
         x = skips[0][0]
+        B = Bm // 2 if supcon else Bm
+        st_head = None
         for i in range(1, 6):
             blend = getattr(fe, f"upsample_blends{i}").blend_conv
             sk = skips[i]
             OH, OW = sk[0].shape[1:3]
-            t = ops.upsample_add(x, sk, OH, OW)
-            bn = self._bn(t, blend.norm, training)
+            if training:                   # the BatchNorm statistics of t ride the kernel that writes it
+                t, st = ops.upsample_add(x, sk, OH, OW, want_stats=True)
+            else:
+                t, st = ops.upsample_add(x, sk, OH, OW), None
+            bn = self._bn(t, blend.norm, training, sums=st)
             z, pro = self._activated(t, bn)
-            xn = ops.conv_fwd(z, blend.conv.weight, 1, 1, pro=pro)
+            if i == 5 and self.seg is not None and training:
+                # the segmentation head's BatchNorm sees the first crop only (weathernet.py:78-82): its statistics are a
+                # prefix of the per-tile sums of the convolution that produces fine_feat
+                xn, st_head = ops.conv_fwd(z, blend.conv.weight, 1, 1, pro=pro, want_stats=True, stats_images=B)
+            else:
+                xn = ops.conv_fwd(z, blend.conv.weight, 1, 1, pro=pro)
             if need_grad:
                 tape.append(("blend", i, x.shape[1:3], t, bn, z, blend))
             x = xn
         fine_feat = x
-        B = Bm // 2 if supcon else Bm
         seg = before = None
         if self.seg is not None:
             h, w = fine_feat.shape[1:3]
             ff0 = fine_feat[:B]
-            bnh = self._bn(ff0, self.seg.norm, training, rows=B * h * w)
+            bnh = self._bn(ff0, self.seg.norm, training, rows=B * h * w, sums=st_head)
             zh, pro = self._activated(ff0, bnh)
             before = ops.conv_fwd(zh, self.seg.conv.weight, 1, 0, bias=self.seg.conv.bias, dst_cs=LOGIT_CS, pro=pro)
             seg = None if lazy_seg else ops.upsample_to_nchw(before, self.num_classes, H, W)

@@ -486,12 +486,15 @@ def pro_ok(Cin):
     return Cin <= PRO_MAXK and os.environ.get("DCS_PROLOGUE", "1") != "0"
 
 
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None, pro=None):
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None, pro=None,
+             stats_images=None):
     """nn.Conv2d forward.  x [N,H,W,Cin]; w OIHW channels_last; -> [N,OH,OW,dst_cs or Cout].
     want_stats: also return sums [1,2,Cout] (per-channel sum / sum of squares of the output) from the fused epilogue.
     koff: x holds the input-channel slice [koff, koff+Cin) of a wider weight (the other slices belong to other
     tensors of a concatenation); out: accumulate into this tensor instead of allocating (sum over the slices).
-    pro: BatchNorm record [4,Cin] of x -- the convolution reads relu(x * scale + shift) (pro_ok(Cin) must hold)."""
+    pro: BatchNorm record [4,Cin] of x -- the convolution reads relu(x * scale + shift) (pro_ok(Cin) must hold).
+    stats_images: the statistics cover the first stats_images images only (the segmentation head normalises the first
+    crop of a two-crop batch, network/weathernet.py:78-82): a prefix of the epilogue's per-tile rows."""
     _req(x)
     N, H, W, Cin = x.shape
     Cout, Ktot, R, S = w.shape
@@ -507,15 +510,23 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1,
         return out
     alloc = torch.zeros if cs != Cout else torch.empty
     y = alloc((N, g.DH, g.DW, cs), device=x.device, dtype=_F32)
+    hw = g.DH * g.DW
+    nimg = N if stats_images is None else int(stats_images)
     if ns > 1:
         _gather_split(x, krsc(w), g, ns, y, False, pro)
-        return (y, colsum(y.reshape(-1, Cout), moments=True)) if want_stats else y
+        return (y, colsum(y.reshape(-1, Cout)[:nimg * hw], moments=True)) if want_stats else y
     if not want_stats:
         _gather(x, krsc(w), bias, y, g, 0, None, pro)
         return y
-    part, G, G1 = _stats_buffer(N * g.DH * g.DW, Cout, x.device)
+    part, G, G1 = _stats_buffer(N * hw, Cout, x.device)
     _gather(x, krsc(w), bias, y, g, 0, part, pro)
-    return y, _stats_reduce(part, G, G1, Cout, N * g.DH * g.DW)
+    if nimg == N:
+        return y, _stats_reduce(part, G, G1, Cout, N * hw)
+    # a prefix of the images: their tiles are the first rows of `part` when no tile (128 or 256 pixels) spans two images
+    Gs = nimg * hw // CONV_BM
+    if hw % 256 == 0 and cs == Cout and (G1 == 0 or Gs % 128 == 0):
+        return y, _stats_reduce(part, Gs, 0 if G1 == 0 else Gs // 128, Cout, nimg * hw)
+    return y, colsum(y.reshape(-1, Cout)[:nimg * hw], moments=True)
 
 
 def pack_dgrad_weight(w, koff=0, kw=None):
@@ -851,12 +862,21 @@ def bn_pool_bwd(g, idx, y, bn, gamma, dgamma=None, dbeta=None, acc_param=False, 
     return dy
 
 
-def upsample_add(x, skips: Sequence[torch.Tensor], OH, OW):
+def upsample_add(x, skips: Sequence[torch.Tensor], OH, OW, want_stats=False):
+    """t = bilinear_upsample(x, (OH, OW)) + sum(skips).  want_stats: also the batch statistics of t (Moments, as from
+    conv_fwd(want_stats=True)) reduced by the same kernel instead of a colsum pass over t."""
     N, IH, IW, Cc = x.shape
     t = torch.empty((N, OH, OW, Cc), device=x.device, dtype=_F32)
     s = list(skips) + [None] * (3 - len(skips))
+    rows = N * OH * OW
+    if want_stats and Cc <= 1024 and 256 % (Cc // 4) == 0 and os.environ.get("DCS_UPSAMPLE_STATS", "1") != "0":
+        groups = int(max(1, min(2048, (rows * (Cc // 4)) // 256)))
+        part = torch.empty((groups, 2, Cc), device=x.device, dtype=_F32)
+        _call("dcs_upsample_add_stats", _p(_req(x)), _p(s[0]), _p(s[1]), _p(s[2]), _p(t), _p(part), groups, N, IH, IW, OH, OW,
+              Cc, _stream())
+        return t, _stats_reduce(part, groups, 0, Cc, rows)
     _call("dcs_upsample_add", _p(_req(x)), _p(s[0]), _p(s[1]), _p(s[2]), _p(t), N, IH, IW, OH, OW, Cc, _stream())
-    return t
+    return (t, colsum(t.reshape(-1, Cc), moments=True)) if want_stats else t
 
 
 def upsample_bwd(g, IH, IW, out=None, accumulate=False):

@@ -234,6 +234,12 @@ int dcs_bn_pool_bwd_apply(const float* g, const uint8_t* idx, const float* y, co
 /* network/utils.py:92-102: t = bilinear(x -> [OH,OW], align_corners=False) + ((s0+s1)+s2). */
 int dcs_upsample_add(const float* x, const float* s0, const float* s1, const float* s2, float* t,
                      int N, int IH, int IW, int OH, int OW, int C, void* stream);
+/* dcs_upsample_add that also reduces the batch statistics of the BatchNorm consuming t (network/utils.py:36-41): partial
+ * [groups][2][C] = per-block sum / sum of squares of the values written (double accumulators, rounded once per block);
+ * groups = the grid (<= 2048, groups * 256 <= N*OH*OW*C/4 + 255), C <= 1024 with 256 % (C/4) == 0; reduce with
+ * dcs_colsum_final(partial, out, 1, groups, C, 1, count). */
+int dcs_upsample_add_stats(const float* x, const float* s0, const float* s1, const float* s2, float* t, float* partial,
+                           int groups, int N, int IH, int IW, int OH, int OW, int C, void* stream);
 /* adjoint of the bilinear part: gx[n,iy,ix,c] (+)= sum_o w(o,i) g[n,oy,ox,c]. */
 int dcs_upsample_bwd(const float* g, float* gx, int N, int IH, int IW, int OH, int OW, int C,
                      int accumulate, void* stream);

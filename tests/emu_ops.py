@@ -58,7 +58,8 @@ class level_batch:
         return False
 
 
-def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None, pro=None):
+def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1, koff=None, out=None, pro=None,
+             stats_images=None):
     if pro is not None:                                 # contract of dcs_conv_gather_pro
         x = F.relu(x * pro[0] + pro[1])
     wk = w if koff is None else w[:, koff:koff + x.shape[-1]]
@@ -66,7 +67,8 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1,
     if out is not None:
         out[..., :y.shape[-1]].add_(y)
         return out
-    sums = colsum(y.reshape(-1, y.shape[-1]), moments=True) if want_stats else None
+    ys = y if stats_images is None else y[:stats_images]
+    sums = colsum(ys.reshape(-1, y.shape[-1]), moments=True) if want_stats else None
     if dst_cs and dst_cs != y.shape[-1]:
         y = F.pad(y, (0, dst_cs - y.shape[-1]))
     return (y.contiguous(), sums) if want_stats else y.contiguous()
@@ -275,12 +277,13 @@ def bn_pool_bwd(g, idx, y, bn, gamma, dgamma=None, dbeta=None, acc_param=False, 
     return dy
 
 
-def upsample_add(x, skips, OH, OW):
+def upsample_add(x, skips, OH, OW, want_stats=False):
     t = F.interpolate(_nchw(x), (OH, OW), mode="bilinear", align_corners=False)
     sk = 0
     for s in skips:
         sk = sk + _nchw(s)
-    return _nhwc(t + sk)
+    t = _nhwc(t + sk)
+    return (t, colsum(t.reshape(-1, t.shape[-1]), moments=True)) if want_stats else t
 
 
 @torch.enable_grad()

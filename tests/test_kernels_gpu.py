@@ -942,3 +942,34 @@ def test_streaming_access_paths_are_bitwise_the_default_paths(ops, monkeypatch):
     assert len(ref) == len(got) >= 17
     for i, (a, b) in enumerate(zip(ref, got)):
         assert torch.equal(a, b), i
+
+
+@pytest.mark.parametrize("N,IH,IW,OH,OW,C,nsk", [(2, 8, 16, 16, 32, 128, 2), (3, 5, 7, 10, 14, 128, 1), (1, 16, 32, 32, 64, 64, 3),
+                                                  (2, 3, 5, 6, 10, 256, 0)])
+def test_upsample_add_with_batch_statistics(ops, monkeypatch, N, IH, IW, OH, OW, C, nsk):
+    """dcs_upsample_add_stats: the same t as dcs_upsample_add (bitwise) and the batch statistics of t from the same
+    launch, against the double-precision moments of t (the reduction pass it replaces is held to the same 2e-5)."""
+    x = rnd(N, IH, IW, C, seed=1).to(DEV)
+    sk = [rnd(N, OH, OW, C, seed=2 + i).to(DEV) for i in range(nsk)]
+    t, st = ops.upsample_add(x, sk, OH, OW, want_stats=True)
+    monkeypatch.setenv("DCS_UPSAMPLE_STATS", "0")
+    t0, st0 = ops.upsample_add(x, sk, OH, OW, want_stats=True)
+    assert torch.equal(t, t0)
+    close(t, E.upsample_add(x.cpu(), [s.cpu() for s in sk], OH, OW), 2e-5, "t")
+    v = t.double().reshape(-1, C)
+    mom = torch.stack([v.mean(0), v.var(0, unbiased=False)])
+    close(st.reshape(2, C), mom, 2e-5, "fused moments")
+    close(st0.reshape(2, C), mom, 2e-5, "separate pass")
+
+
+def test_conv_statistics_over_the_first_images(ops):
+    """conv_fwd(stats_images=B): statistics of the first B images from a prefix of the epilogue's per-tile sums (the
+    segmentation head's BatchNorm sees the first crop of a two-crop batch), one- and two-level reductions."""
+    for (N, B, H, W, Cin, Cout) in [(4, 2, 16, 32, 64, 128), (6, 3, 256, 512, 64, 64)]:
+        x = rnd(N, H, W, Cin, seed=5).to(DEV)
+        w = cl(rnd(Cout, Cin, 3, 3, seed=6, scale=0.05)).to(DEV)
+        y, st = ops.conv_fwd(x, w, 1, 1, want_stats=True, stats_images=B)
+        v = y[:B].double().reshape(-1, Cout)
+        close(st.reshape(2, Cout), torch.stack([v.mean(0), v.var(0, unbiased=False)]), 2e-5, (N, B, H, W))
+        y_all, st_all = ops.conv_fwd(x, w, 1, 1, want_stats=True)
+        assert torch.equal(y, y_all)
