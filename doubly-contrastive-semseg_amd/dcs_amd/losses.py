@@ -401,9 +401,26 @@ def _contrast_rows(X, y, temperature, row_gather, cap):
     return loss, dX_all[start:start + X.shape[0]].contiguous()
 
 
+def _row_sink(feats):
+    """The autograd node that produced ``feats`` if it accepts the gradient of a few rows directly (model._SwiftNetFn for
+    its fine_feat0 output, reached through the NHWC -> NCHW permute of WeatherNet.forward), else None.  The pixel
+    contrast touches <= 608 of the 2 million pixels of fine_feat0: handing the node those rows saves a 1 GB zero fill and
+    a 3 GB add per step at C3; any other producer gets the dense gradient."""
+    if os.environ.get("DCS_SPARSE_FF0", "1") == "0":
+        return None
+    gf = getattr(feats, "grad_fn", None)
+    if gf is None or type(gf).__name__ != "PermuteBackward0" or len(gf.next_functions) != 1:
+        return None
+    node, index = gf.next_functions[0]
+    fwd = getattr(node, "_forward_cls", None)           # custom autograd.Function nodes name their Function class
+    if fwd is None or not hasattr(fwd, "accept_rows") or index != getattr(fwd, "rows_output", -1):
+        return None
+    return node
+
+
 class _PixelContrastFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, feats, rowidx, y, temperature, row_gather=None, cap=0):
+    def forward(ctx, feats, rowidx, y, temperature, row_gather=None, cap=0, sink=None):
         v = nhwc(feats.detach())
         N, H, W, Cc = v.shape
         if rowidx.numel():
@@ -411,18 +428,25 @@ class _PixelContrastFn(torch.autograd.Function):
         else:
             X = torch.empty((0, Cc), device=v.device, dtype=v.dtype)
         loss, dX = _contrast_rows(X, y, temperature, row_gather, cap)
-        ctx.saved = (dX, rowidx, (N, H, W, Cc))
+        ctx.saved = (dX, rowidx, (N, H, W, Cc), sink)
         return loss.reshape(()).clone()
 
     @staticmethod
     def backward(ctx, g):
-        dX, rowidx, (N, H, W, Cc) = ctx.saved
+        dX, rowidx, (N, H, W, Cc), sink = ctx.saved
         ctx.saved = None
-        gfeat = torch.zeros((N, H, W, Cc), device=dX.device, dtype=dX.dtype)
         if rowidx.numel():
             ops.scale_inplace(dX, _scalar(g))
+        if sink is not None:
+            # the rows go to the producer directly; autograd gets a zero that occupies no memory (and stays correct if it
+            # is summed with another consumer's gradient)
+            if rowidx.numel():
+                sink._forward_cls.accept_rows(sink, rowidx, dX)
+            return dX.new_zeros(()).expand(N, Cc, H, W), None, None, None, None, None, None
+        gfeat = torch.zeros((N, H, W, Cc), device=dX.device, dtype=dX.dtype)
+        if rowidx.numel():
             ops.scatter_add_rows(dX, rowidx, gfeat)
-        return gfeat.permute(0, 3, 1, 2), None, None, None, None, None
+        return gfeat.permute(0, 3, 1, 2), None, None, None, None, None, None
 
 
 class LazyUpsampled:
@@ -671,4 +695,4 @@ class PixelContrastLoss(nn.Module, ABC):
         if isinstance(feats, LazyUpsampled):
             return _PixelContrastLazyFn.apply(feats.lowres, rowidx, y, float(self.temperature), self.row_gather,
                                               feats.size, cap)
-        return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature), self.row_gather, cap)
+        return _PixelContrastFn.apply(feats, rowidx, y, float(self.temperature), self.row_gather, cap, _row_sink(feats))

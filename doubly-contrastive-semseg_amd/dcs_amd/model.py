@@ -191,7 +191,7 @@ class FlatBuffers:
 
 
 class _Saved:
-    __slots__ = ("tape", "shapes", "training", "B", "Bm")
+    __slots__ = ("tape", "shapes", "training", "B", "Bm", "ff_shape")
 
 
 class SwiftNetEngine:
@@ -321,6 +321,7 @@ class SwiftNetEngine:
         if need_grad:
             saved = _Saved()
             saved.tape, saved.training, saved.B, saved.Bm = tape, training, B, Bm
+            saved.ff_shape = tuple(fine_feat.shape)
         return seg, before, fine_feat, saved
 
     @staticmethod
@@ -537,6 +538,14 @@ class _SwiftNetFn(torch.autograd.Function):
     view that is its own autograd output: the pixel-contrast gradient then arrives separately instead of going
     through autograd's split-backward (a 2 GB cat + add per step at C3))."""
 
+    rows_output = 3        # index of fine_feat0 among the outputs: the one that takes row gradients (losses._row_sink)
+
+    @staticmethod
+    def accept_rows(ctx, rowidx, rows):
+        """Gradient of fine_feat0 given as rows [A, C] at pixel rows ``rowidx`` (int32 into [B*h*w]); added in backward.
+        ``ctx`` is the autograd node of one forward call (its ``_forward_cls`` is this class)."""
+        ctx.row_grads = (getattr(ctx, "row_grads", None) or []) + [(rowidx, rows)]
+
     @staticmethod
     def forward(ctx, engine: SwiftNetEngine, img, training, supcon, grad_enabled, lazy_seg, *params):
         need_grad = grad_enabled and any(p.requires_grad for p in params)
@@ -557,6 +566,10 @@ class _SwiftNetFn(torch.autograd.Function):
         # both gradient buffers are consumed in place: they are freshly produced by the loss nodes
         if g_ff is not None:
             g_ff = g_ff.contiguous()
+        row_grads = getattr(ctx, "row_grads", None) or []
+        ctx.row_grads = None
+        if g_ff0 is not None and row_grads and all(st == 0 for st in g_ff0.stride()):
+            g_ff0 = None                        # the memory-less zero of losses._PixelContrastFn: its rows came separately
         if g_ff0 is not None:
             g_ff0 = g_ff0.contiguous()
             if g_ff is None:
@@ -567,6 +580,12 @@ class _SwiftNetFn(torch.autograd.Function):
                     g_ff[:g_ff0.shape[0]].copy_(g_ff0)
             else:
                 ops.axpy(g_ff[:g_ff0.shape[0]], g_ff0, 1.0)
+        if row_grads:
+            if g_ff is None:
+                rows0 = row_grads[0][1]
+                g_ff = torch.zeros(ctx.saved.ff_shape, device=rows0.device, dtype=rows0.dtype)
+            for rowidx, rows in row_grads:
+                ops.scatter_add_rows(rows, rowidx, g_ff)
         if g_seg is not None:
             g_seg = g_seg.contiguous()
         grads = ctx.engine.backward(ctx.saved, g_seg if ctx.has[0] else None,

@@ -248,3 +248,29 @@ def test_library_sampler_plan_is_what_the_criterion_uses(monkeypatch):
     b = losses.plan_anchor_requests(cnt, 3, 1024, 2)
     assert a == b and torch.equal(sa, torch.rand(3))
     assert a[0] == 2 and a[1] == 5 and len(a[2]) == 10
+
+
+@pytest.mark.parametrize("criterion,two", [("supcon_pixelcontrast_focal", True), ("pixelcontrast_focal", False)])
+def test_pixel_contrast_row_gradients_equal_the_dense_gradient(emu, monkeypatch, criterion, two):
+    """losses._row_sink: the pixel-contrast gradient reaches the network as <= 608 rows handed to the autograd node of
+    fine_feat0 (a memory-less zero goes through autograd) instead of a dense tensor that is zero almost everywhere.  Same
+    step, same gradients as the dense route (DCS_SPARSE_FF0=0); and the sink is really taken."""
+    from dcs_amd import losses, model
+    b = 2
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, 128, 256, seed=21, two_crops=two, cell=32)
+    taken = []
+    orig = model._SwiftNetFn.accept_rows
+    monkeypatch.setattr(model._SwiftNetFn, "accept_rows", staticmethod(lambda ctx, r, x: (taken.append(int(r.numel())), orig(ctx, r, x))[1]))
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("DCS_SPARSE_FF0", mode)
+        ts = build(criterion, batch_size=b)
+        s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        torch.manual_seed(9)
+        out = ts.step((s0, dict(left=img[b:])) if two else s0, do_optimizer_step=False)
+        res.append((float(out["total"]), {k: p.grad.clone() for k, p in ts.model.named_parameters() if p.grad is not None}))
+    assert len(taken) == 1 and taken[0] > 0                         # only the first run handed rows over
+    assert res[0][0] == res[1][0]
+    assert res[0][1].keys() == res[1][1].keys() and len(res[0][1]) > 60
+    for k in res[0][1]:
+        assert torch.allclose(res[0][1][k], res[1][1][k], rtol=1e-6, atol=1e-9), k
