@@ -497,17 +497,27 @@ class SwiftNetEngine:
                                                  y1.numel() // y1.shape[-1], momentum=blk.bn1.momentum)
                                 self._nbt.append(blk.bn1)
                             wgrad(blk.conv1, x, dy1, s, 1)
-                            if blk.downsample is not None:
-                                dyd, _ = bn_bwd(blk.downsample[1], gm, yd, bnd)
-                                wgrad(blk.downsample[0], x, dyd, s, 0)
-                                g_in = ops.conv_dgrad(dyd, wp(blk.downsample[0]), x.shape[1:3], s, 0)
-                            else:
-                                g_in = gm
                             # conv1's data gradient is the last writer of this block's input gradient unless a skip
                             # projection follows (first block of a layer: the next tape item is then "skip", not "block")
                             cb = consumer_bnb(lt, at - 1)
-                            r = ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1, out=g_in, accumulate=True, bnb=cb)
-                            g_cur, cur_sums = r if cb is not None else (r, None)
+                            if blk.downsample is not None:
+                                dyd, _ = bn_bwd(blk.downsample[1], gm, yd, bnd)
+                                wgrad(blk.downsample[0], x, dyd, s, 0)
+                            if blk.downsample is not None and cb is None:
+                                # conv1 (3x3) writes every pixel of the input gradient, the 1x1 / stride-s projection
+                                # then adds its one parity class: no zero fill of the other three, a quarter of the
+                                # accumulate reads (the sum of the two terms is the same either way round)
+                                g_in = ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1)
+                                g_cur = ops.conv_dgrad(dyd, wp(blk.downsample[0]), x.shape[1:3], s, 0, out=g_in,
+                                                       accumulate=True)
+                                cur_sums = None
+                            else:
+                                if blk.downsample is not None:
+                                    g_in = ops.conv_dgrad(dyd, wp(blk.downsample[0]), x.shape[1:3], s, 0)
+                                else:
+                                    g_in = gm
+                                r = ops.conv_dgrad(dy1, wp(blk.conv1), x.shape[1:3], s, 1, out=g_in, accumulate=True, bnb=cb)
+                                g_cur, cur_sums = r if cb is not None else (r, None)
                         elif kind == "stem":
                             _, _, p, y, bn, pidx, bnm = item
                             acc = bnm.weight in grads
