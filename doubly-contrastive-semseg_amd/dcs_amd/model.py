@@ -10,6 +10,7 @@ reverse pass through ``dcs_amd.ops`` and is exposed to autograd as ONE
 """
 from __future__ import annotations
 
+import os
 from itertools import chain
 from typing import Dict, List, Optional
 
@@ -659,11 +660,57 @@ class WeatherNet(nn.Module):
                                                                self.num_classes))
         return self._engine
 
+    def _graphed_eval(self, parts, supcon):
+        """Eval-mode forward without autograd as ONE hipGraph launch (opts.eval_graph / DCS_EVAL_GRAPH=1).
+
+        The inference forward of a single 2048x1024 image is ~250 kernels of 5-50 us each: issued one by one the step is
+        bounded by the host (Python + launch path, ~15 us per kernel), not by the device.  The whole forward is therefore
+        captured once per (input shapes, parameter storage) into a HIP graph -- the library's launches go to torch's
+        current stream, so stream capture records them like any torch kernel; level batches are merged at capture time --
+        and later calls copy the images into the graph's static input and replay it.  Parameters and BatchNorm running
+        statistics are read through their own storage at every replay (an optimizer step in between is seen).  The
+        OUTPUTS are the graph's static tensors: they are overwritten by the next call with the same shapes (the validate
+        loop, trainer.py:303-402 of the reference, consumes them at once)."""
+        key = (tuple(tuple(t.shape) for t in parts), bool(supcon), next(self.parameters()).data_ptr(),
+               self.segmentation is not None)
+        cache = self.__dict__.setdefault("_eval_graphs", {})
+        ent = cache.get(key)
+        engine = self._get_engine()
+        if ent is None:
+            static_in = [t.clone() for t in parts]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                   # every kernel variant is loaded before the capture
+                engine.forward(static_in, False, supcon, False, False)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                outs = engine.forward(static_in, False, supcon, False, False)
+            ent = cache[key] = (graph, static_in, outs)
+            if len(cache) > 8:                              # a handful of resolutions at most (graphs hold their activations)
+                cache.pop(next(iter(cache)))
+        graph, static_in, outs = ent
+        for d, t in zip(static_in, parts):
+            d.copy_(t)
+        graph.replay()
+        return outs[:3]
+
     def forward(self, left_img, return_supcon_feature=False):
         """left_img: [Bm,3,H,W] raw 0-255 image batch, or a list of batch parts (e.g. the two crops of the
         ``supcon*`` criteria, equivalent to their torch.cat along dim 0 without the copy)."""
         for t in (left_img if isinstance(left_img, (list, tuple)) else [left_img]):
             ops.require_device(t, "left_img")
+        if (not self.training and not torch.is_grad_enabled() and
+                (getattr(self.opts, "eval_graph", False) or os.environ.get("DCS_EVAL_GRAPH", "0") == "1")):
+            parts = list(left_img) if isinstance(left_img, (list, tuple)) else [left_img]
+            parts = [t if t.is_floating_point() else t.float() for t in parts]
+            seg, before, ff = self._graphed_eval(parts, bool(return_supcon_feature))
+            B = ff.shape[0] // 2 if return_supcon_feature else ff.shape[0]
+            fine_feat = ff.permute(0, 3, 1, 2)
+            fine_feat0 = ff[:B].permute(0, 3, 1, 2)
+            if self.segmentation is None:
+                return None, None, fine_feat, fine_feat0
+            return seg, before[..., :self.num_classes].permute(0, 3, 1, 2), fine_feat, fine_feat0
         params = [p for p in self.parameters()]
         # training with autograd on: pred_segmap is a LazyLogits handle (losses.py) -- the criteria evaluate it fused,
         # any other use materialises it; opts.lazy_pred_segmap = False restores the eager 2.55 GB tensor

@@ -408,3 +408,39 @@ def test_reference_style_loop_with_torch_adam_matches_trainstep():
             assert torch.equal(va, vb), k
         elif "running" in k:
             close(vb, va.cpu(), 1e-5, k)
+
+
+def test_graphed_eval_forward_is_the_eager_eval_forward(monkeypatch):
+    """opts.eval_graph / DCS_EVAL_GRAPH=1: the eval-mode forward captured into one hipGraph launch (model._graphed_eval)
+    returns BITWISE the tensors of the launch-by-launch forward -- at capture, on replay with another input, and after the
+    parameters changed in place (the graph reads them through their storage); a second resolution gets its own graph."""
+    from dcs_amd.model import WeatherNet
+    from dcs_amd.trainer import make_opts
+    model = WeatherNet(make_opts(), num_classes=19, device=DEV, backbone="resnet18", train_semantic=True).to(DEV).eval()
+    model.load_state_dict(O.make_state(seed=1), strict=True)
+    imgs = [O.synthetic_batch(2, 128, 256, seed=s, cell=32)[0].to(DEV) for s in (1, 2)]
+    big = O.synthetic_batch(1, 256, 256, seed=3, cell=32)[0].to(DEV)
+
+    def eager(x):
+        monkeypatch.setenv("DCS_EVAL_GRAPH", "0")
+        with torch.no_grad():
+            return [t.clone() for t in model(x)]
+
+    def graphed(x):
+        monkeypatch.setenv("DCS_EVAL_GRAPH", "1")
+        with torch.no_grad():
+            return [t.clone() for t in model(x)]
+
+    for x in (imgs[0], imgs[1], imgs[0], big, imgs[1]):
+        for a, b in zip(eager(x), graphed(x)):
+            assert torch.equal(a, b)
+    assert len(model._eval_graphs) == 2
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.01)                                   # an optimizer step between two validations
+    for a, b in zip(eager(imgs[0]), graphed(imgs[0])):
+        assert torch.equal(a, b)
+    monkeypatch.setenv("DCS_EVAL_GRAPH", "1")
+    model.train()
+    out = model(imgs[0])                                   # training / autograd never takes the graph
+    assert out[2].requires_grad
