@@ -169,7 +169,7 @@ def roofline(g, wg, args, world):
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md)",
             "algorithmic_bytes_per_launch": g.get("alg_bytes_per_launch"),
             "algorithmic_flops_per_launch": g.get("alg_flops_per_launch"),
-            "kernel": "conv_gather_x3_kernel / conv_gather_kernel (conv forward + data gradient; fp32 operands as three "
+            "kernel": "conv3x3_x3w[_multi]_kernel / conv_gather_x3[_multi]_kernel / conv_gather_kernel (conv forward + data gradient, the pyramid levels of a layer in one launch; fp32 operands as three "
                       "bf16 pieces on v_mfma_f32_32x32x16_bf16, the rest exact fp32 on v_mfma_f32_32x32x2_f32)",
             "launches_per_step": g["launches"] // max(args.steps, 1), "avg_launch_us": g["avg_us"],
             "ms_per_step": g["ms"] / max(args.steps, 1),
