@@ -105,6 +105,30 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
     __builtin_amdgcn_wave_barrier();
     const int c4 = lane % EPV, rr = lane / EPV;
     const int colv = co0 + wn * EPC + c4 * 4;
+    // Everything the read-back passes LOAD from global memory (old destination values, the BatchNorm-backward operands)
+    // is requested up front: the stores of pass p and the loads of pass p + 1 go through pointers the compiler cannot
+    // tell apart, so inside the loop every load would wait behind the previous store -- eight (sixteen) serial HBM
+    // latencies per 32-row sub-tile.
+    constexpr int NP = 32 / EPR;
+#ifdef DCS_EPI_NO_PREFETCH
+    constexpr bool PRE = false;               // A/B switch (compile time)
+#else
+    constexpr bool PRE = NP <= 8;
+#endif
+    float4 pre_o[PRE ? NP : 1], pre_y[PRE ? NP : 1], pre_m[PRE ? NP : 1];
+    const bool vrow = vec_ok && colv + 3 < Cout;
+    if (PRE && vrow && (acc_dst || do_bnb)) {
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const long long ro = rowoff[row0 + p * EPR + rr];
+        if (ro < 0) continue;
+        if (acc_dst) pre_o[p] = ld4s(dst + ro + colv, nt);
+        if (do_bnb) {
+          pre_y[p] = ld4s(bnb.y + ro + colv, nt);
+          if (bnb.mask) pre_m[p] = ld4s(bnb.mask + ro + colv, nt);
+        }
+      }
+    }
 #pragma unroll
     for (int p = 0; p < 32 / EPR; ++p) {
       const int rl = p * EPR + rr;
@@ -113,13 +137,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
       float4 v = ld4(&stg[rl * EPL + c4 * 4]);
       float* q = dst + ro + colv;
       if (vec_ok && colv + 3 < Cout) {
-        if (acc_dst) { const float4 o = ld4s(q, nt); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (acc_dst) { const float4 o = PRE ? pre_o[PRE ? p : 0] : ld4s(q, nt); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
         st4s(q, v, nt);
         if (do_bnb) {
-          const float4 yy = ld4s(bnb.y + ro + colv, nt);
+          const float4 yy = PRE ? pre_y[PRE ? p : 0] : ld4s(bnb.y + ro + colv, nt);
           float4 gm = v;
           if (bnb.mask) {
-            const float4 ms = ld4s(bnb.mask + ro + colv, nt);
+            const float4 ms = PRE ? pre_m[PRE ? p : 0] : ld4s(bnb.mask + ro + colv, nt);
             gm.x = ms.x > 0.f ? gm.x : 0.f; gm.y = ms.y > 0.f ? gm.y : 0.f; gm.z = ms.z > 0.f ? gm.z : 0.f; gm.w = ms.w > 0.f ? gm.w : 0.f;
           } else if (bnb.relu) {
             gm.x = fmaf(yy.x, b_sc.x, b_sh.x) > 0.f ? gm.x : 0.f; gm.y = fmaf(yy.y, b_sc.y, b_sh.y) > 0.f ? gm.y : 0.f;
