@@ -207,7 +207,7 @@ def cpu_baseline(O, args):
 def pmc_traffic(args, world):
     """HBM bytes per conv_gather launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r02_k_pmc_traffic_c3.json")
+    path = os.path.join(ROOT, "profiles", "r02_l_pmc_traffic_c3.json")
     default = (args.batch, args.height, args.width, args.criterion, args.model) == \
         (16, 1024, 2048, "supcon_pixelcontrast_focal", "resnet18")
     if not (default and os.path.exists(path)):
