@@ -626,6 +626,10 @@ class PixelContrastLoss(nn.Module, ABC):
         self.last_anchors = None          # (img [T], cls [T], pix [T, n_view]) of the last call, for tests
         self.row_gather = None            # set by dcs_amd.dist.DataParallelStep
         self.gather_cap = 0               # rows every rank contributes to the all-gather (<= max_samples)
+        # parity-test hook: (img [T], pix [T, n_view], cls [T]) -- evaluate the loss on THESE anchors instead of sampling
+        # (what tests/golden/make_golden.py::pixel_loss does to the reference for its float64 run): decouples the loss /
+        # gradient comparison from argmax near-ties of the forward pass that redirect the sampler.  Consumed by one call.
+        self.forced_anchors = None
 
     def _count(self, feats, labels, predict):
         """Device half of the sampler (argmax, nearest label downsample, per-class hard/easy histogram) and the
@@ -667,11 +671,22 @@ class PixelContrastLoss(nn.Module, ABC):
         if pre["event"] is not None:
             pre["event"].synchronize()                        # one host wait per step (reference: ~3 per class)
         counts = pre["counts"]
-        plan = plan_anchor_requests(counts, nc, self.max_samples, self.max_views)
+        forced, self.forced_anchors = self.forced_anchors, None
+        plan = plan_anchor_requests(counts, nc, self.max_samples, self.max_views) if forced is None else None
         if self.temperature != self.base_temperature:
             raise NotImplementedError("temperature != base_temperature")
         cap = int(self.gather_cap or self.max_samples)
-        if plan is None:
+        if forced is not None:
+            img, pixv, cls = forced
+            pix_t = torch.as_tensor(pixv, dtype=torch.int32).reshape(len(img), -1)          # [T, n_view]
+            T, n_view = pix_t.shape
+            base = torch.as_tensor(img, dtype=torch.int32).reshape(T, 1) * (h * w)
+            pix = pix_t.t().contiguous().to(feats.device)                                   # view-major, like below
+            rowidx = (pix_t + base).t().contiguous().view(-1).to(feats.device)
+            cls = [float(c) for c in cls]
+            y = torch.tensor(cls * n_view, dtype=torch.float32).to(feats.device)
+            self.last_anchors = ([int(i) for i in img], cls, pix, n_view)
+        elif plan is None:
             if self.row_gather is None:
                 raise AttributeError("'NoneType' object has no attribute 'shape'")   # loss.py:341 on (None, None)
             # data parallel: THIS rank's shard has no class with enough pixels, the global batch may well have.  The rank

@@ -26,13 +26,13 @@ def run_workers(out, device):
     return [torch.load(os.path.join(out, f"rank{r}.pt"), weights_only=True) for r in range(2)]
 
 
-def single_process(criterion, seed, device, eval_bn=True):
+def single_process(criterion, seed, device, eval_bn=True, deeplab=False):
     """The same global batch in ONE process (no row gather, no all-reduce)."""
     sys.path.insert(0, HERE)
     from dist_worker import build, shard_sample
-    B, h, w = 2, 128, 256
-    batch = O.synthetic_batch(B, h, w, seed=seed, two_crops=True, cell=32)
-    ts = build(criterion, B, batch[4], device=device)
+    B, h, w = (2, 96, 160) if deeplab else (2, 128, 256)
+    batch = O.synthetic_batch(B, h, w, seed=seed, two_crops=True, cell=16 if deeplab else 32)
+    ts = build(criterion, B, batch[4], device=device, deeplab=deeplab)
     if eval_bn:
         ts.model.eval()
     out = ts.step(shard_sample(batch, 0, B, True, B))
@@ -54,17 +54,19 @@ def check_equals_single_process(r0, r1, prefix, ts, out, loss_rtol=1e-5, grad_rt
         assert torch.equal(r0[prefix + "_grads"][k], r1[prefix + "_grads"][k]), k       # all-reduce leaves identical bits
 
 
-def check_training_mode(r0, r1):
-    for k in ("B_total", "B_supcon", "B_pixel", "B_seg"):
-        assert float(r0[k]) == float(r1[k]), k
-    assert torch.equal(r0["B_param_checksum"], r1["B_param_checksum"])
-    X, y = r0["B_pixel_rows"], r0["B_pixel_labels"]
-    assert torch.equal(X, r1["B_pixel_rows"])
-    assert X.shape[0] == int(r0["B_local_anchor_count"]) + int(r1["B_local_anchor_count"])
+def check_training_mode(r0, r1, prefix="B", images_per_rank=1):
+    P = prefix + "_"
+    for k in ("total", "supcon", "pixel", "seg"):
+        assert float(r0[P + k]) == float(r1[P + k]), k
+    assert torch.equal(r0[P + "param_checksum"], r1[P + "param_checksum"])
+    X, y = r0[P + "pixel_rows"], r0[P + "pixel_labels"]
+    assert torch.equal(X, r1[P + "pixel_rows"])
+    assert X.shape[0] == int(r0[P + "local_anchor_count"]) + int(r1[P + "local_anchor_count"])
+    assert int(r0[P + "local_anchor_count"]) > 0 and int(r1[P + "local_anchor_count"]) > 0
     # fixed-shape gather: 2 ranks x cap rows (cap = max_views * 19 classes * 1 image per rank), padding rows labelled -1
-    assert int(r0["B_gathered_rows"]) == 2 * 38
+    assert int(r0[P + "gathered_rows"]) == 2 * 38 * images_per_rank
     want = O.pixel_contrastive(X.unsqueeze(1), y)
-    assert abs(float(want) - float(r0["B_pixel"])) < 1e-5 * abs(float(want))
+    assert abs(float(want) - float(r0[P + "pixel"])) < 1e-5 * abs(float(want))
 
 
 def check_empty_rank(r0, r1):

@@ -21,14 +21,24 @@ class _MP:
         setattr(obj, name, val)
 
 
-def build(criterion, global_batch, cw, device=None):
+def build(criterion, global_batch, cw, device=None, deeplab=False, lazy=False):
+    """deeplab=True: BASELINE config 5's model (DeepLabV3+ / ResNet-101) on the well-conditioned seeded state."""
     from dcs_amd.trainer import TrainStep, make_opts
     from oracle import swiftnet_oracle as O
-    ts = TrainStep(make_opts(criterion=criterion, batch_size=global_batch), class_weight=cw, device=device or DEVICE)
-    ts.model.load_state_dict(O.make_state(seed=1), strict=True)
+    kw = dict(deeplab=True, model="deeplabv3plus_resnet101", lazy_fine_feat0=lazy) if deeplab else {}
+    ts = TrainStep(make_opts(criterion=criterion, batch_size=global_batch, **kw), class_weight=cw, device=device or DEVICE)
+    if deeplab:
+        from oracle import deeplab_oracle as D
+        ts.model.load_state_dict(D.make_state(seed=7, residual_gain=0.25), strict=True)
+        proj = O.make_proj(seed=9, dim_in=2048)
+        # dropout keep mask from the CPU generator, like F.dropout in the reference (each rank seeds its own stream)
+        ts.model._get_engine().dropout_noise = lambda shape: torch.empty(shape).bernoulli_(0.9)
+    else:
+        ts.model.load_state_dict(O.make_state(seed=1), strict=True)
+        proj = O.make_proj(seed=2)
     with torch.no_grad():
         p = ts.supcon_criterion.projection
-        for dst, src in zip((p[0].weight, p[0].bias, p[2].weight, p[2].bias), O.make_proj(seed=2)):
+        for dst, src in zip((p[0].weight, p[0].bias, p[2].weight, p[2].bias), proj):
             dst.copy_(src)
     return ts
 
@@ -117,6 +127,33 @@ def main(rank, world, port, outdir):
     res["D_local_anchor_count"] = torch.tensor(len(ts.pixelcontrast_criterion.last_anchors[1]) *
                                                ts.pixelcontrast_criterion.last_anchors[3])
     res["D_param_checksum"] = torch.stack([cpu(p).double().sum() for p in ts.model.parameters()])
+    # ---- scenario E (BASELINE config 5's model under the same wrapper): DeepLabV3+ / ResNet-101, eval-mode BatchNorm
+    #      (dropout off) => the DP step on two half-batches equals the single-process step on the full batch
+    captured.clear()
+    hd, wd = 96, 160
+    batch = O.synthetic_batch(B, hd, wd, seed=49, two_crops=True, cell=16)
+    ts = build("supcon_focal", B, batch[4], deeplab=True)
+    ts.model.eval()
+    dp = DataParallelStep(ts, rank, world)
+    out = dp.step(shard_sample(batch, rank, rank + 1, True, B))
+    res["E_total"] = cpu(out["total"].reshape(()))
+    res["E_grads"] = {k: cpu(p.grad) for k, p in ts.model.named_parameters() if p.grad is not None}
+    # ---- scenario F: DeepLab, training mode, doubly-contrastive with the lazy 2048-channel fine_feat0: per-rank sampling,
+    #      global denominators over 2048-wide anchor rows, flat-bucket all-reduce of the 58.7 M-parameter gradient
+    captured.clear()
+    Bf = 4                       # 2 labelled images per rank: the ASPP pooling branch's BatchNorm needs > 1 value per channel
+    batch = O.synthetic_batch(Bf, hd, wd, seed=50, two_crops=True, cell=16)
+    ts = build("supcon_pixelcontrast_focal", Bf, batch[4], deeplab=True, lazy=True)
+    dp = DataParallelStep(ts, rank, world)
+    torch.manual_seed(200 + rank)
+    out = dp.step(shard_sample(batch, 2 * rank, 2 * rank + 2, True, Bf))
+    for k in ("total", "supcon", "pixel", "seg"):
+        res["F_" + k] = cpu(out[k].reshape(()))
+    pix = [c for c in captured if c[2] == 0][0]
+    res["F_pixel_rows"], res["F_pixel_labels"], res["F_gathered_rows"] = pix[0], pix[1], torch.tensor(pix[3])
+    res["F_local_anchor_count"] = torch.tensor(len(ts.pixelcontrast_criterion.last_anchors[1]) *
+                                               ts.pixelcontrast_criterion.last_anchors[3])
+    res["F_param_checksum"] = torch.stack([cpu(p).double().sum() for p in ts.model.parameters()])
     ops.contrast_fwd_bwd = orig
     torch.save(res, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()

@@ -24,12 +24,12 @@ def _gpu():
         pytest.skip("needs a GPU")
 
 
-def build(b, cw, lazy=False):
+def build(b, cw, lazy=False, residual_gain=1.0):
     from dcs_amd.trainer import TrainStep, make_opts
     opts = make_opts(criterion="supcon_pixelcontrast_focal", batch_size=b, deeplab=True, model="deeplabv3plus_resnet101",
                      lazy_fine_feat0=lazy)
     ts = TrainStep(opts, class_weight=cw, device=DEV)
-    ts.model.load_state_dict(D.make_state(seed=7), strict=True)
+    ts.model.load_state_dict(D.make_state(seed=7, residual_gain=residual_gain), strict=True)
     with torch.no_grad():
         p = ts.supcon_criterion.projection
         for dst, src in zip((p[0].weight, p[0].bias, p[2].weight, p[2].bias), O.make_proj(seed=9, dim_in=2048)):
@@ -44,7 +44,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-def _argmax_budget(bud, seg, g, g64):
+def _argmax_budget(bud, seg, g, g64, logits_stride):
     """Class ids: every pixel that differs from the reference's float32 result must be one the reference itself cannot
     decide in float32 (its margin <= 2K x its own fp32 logit error); the count may not exceed K x the reference's own
     fp32-vs-fp64 count (+ a floor of 8 pixels)."""
@@ -57,52 +57,76 @@ def _argmax_budget(bud, seg, g, g64):
     bud.note("argmax", mismatches_hip_vs_ref32=n_bad, mismatches_ref32_vs_ref64=n_ref, pixels=int(bad.size),
              worst_ref_margin_at_mismatch=worst, ref32_logit_abs_err=e32_abs)
     bud.check_abs("argmax mismatch count", n_bad, K * n_ref + 8)
-    bud.check_abs("argmax worst reference margin at a mismatch", worst, 2 * K * e32_abs * 1.002)
+    bud.check_abs("argmax worst reference margin at a mismatch", worst, 2 * K * e32_abs * 1.002 + 1e-3 * worst)
+
+
+# name -> (batch, height, width, data seed, generator seed, residual gain, well conditioned):
+# tests/golden/make_golden_deeplab.py::FIXTURES
+STEP_FIXTURES = {
+    "deeplab_step_b2_128x256": (2, 128, 256, 51, 321, 1.0, False),
+    "deeplab_step_b4_256x512": (4, 256, 512, 53, 322, 0.25, True),
+}
 
 
 @pytest.mark.parametrize("lazy", [False, True])
-def test_deeplab_step_matches_reference_golden(golden_dir, lazy, monkeypatch):
-    """The anchors are sampled from the argmax-derived hard / easy split of the 1/4-resolution predictions; on this
-    101-layer fixture ~0.3 % of the argmax decisions are near-ties that flip between two fp32 evaluations (the reference's
-    own fp32 and fp64 runs disagree on 131 pixels), so the sampled pixels are only reproducible for ONE rounding of the
-    forward pass.  The forward-output budgets are always applied to the default (split-bf16) run; the anchor-dependent
-    part (losses, gradients) is applied to that run when it drew the reference's anchors and otherwise to a run with the
-    exact-fp32 MFMA kernels (DCS_CONV_X3=0) -- which must then draw them."""
-    g = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.npz"), allow_pickle=False)
-    g64 = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.f64.npz"), allow_pickle=False)
-    e32 = lambda k: g64["e32::" + k]
-    b = 2
-    img, labels, ldw, weather, cw = O.synthetic_batch(b, 128, 256, seed=51, two_crops=True, cell=32)
-    bud = Budget(f"gpu_deeplab_step_b2_128x256_lazy{int(lazy)}")
+@pytest.mark.parametrize("name", list(STEP_FIXTURES))
+def test_deeplab_step_matches_reference_golden(golden_dir, name, lazy):
+    """Everything here runs on the DEFAULT kernels (split-bf16 MFMA convolutions: the benched path).
 
-    def run():
-        ts_ = build(b, cw, lazy=lazy)
+    The anchors are sampled from the argmax-derived hard / easy split of the 1/4-resolution predictions, so ONE argmax
+    near-tie that falls the other way redirects the sampler (the reference does it to itself: its channels_last run
+    draws other pixels than its default run on both fixtures, its fp32 and fp64 runs disagree on 131 / 18 class ids).
+    The forward budgets and the sampler's result are taken on the free run; when that run did not draw the fixture's
+    pixels, the anchor-dependent part (losses, gradients, running statistics) is taken from a second run of the SAME
+    kernels with the fixture's anchors injected (PixelContrastLoss.forced_anchors -- what make_golden.pixel_loss does to
+    the reference for its float64 run).
+
+    deeplab_step_b2_128x256 is ill-conditioned (random 101-layer init, deepest maps 8x16: the reference's own fp32 run is
+    2e-3 / 4e-2 from its fp64 run on logits / gradient norms) and is held to K x the reference's own error only;
+    deeplab_step_b4_256x512 (8 crops of 256x512, residual gain 0.25; reference 2e-5 / 2e-3) ALSO meets the north star's
+    1e-3 on logits / features / losses and 1e-2 on every gradient norm in absolute terms."""
+    b, h, w, dseed, rseed, gain, well = STEP_FIXTURES[name]
+    g = np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+    g64 = np.load(os.path.join(golden_dir, name + ".f64.npz"), allow_pickle=False)
+    e32 = lambda k: g64["e32::" + k]
+    sb, sfc, sfs, s0c, s0s, sl = (int(v) for v in g["sub_strides"]) if "sub_strides" in g.files else (1, 8, 1, 16, 2, 4)
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=dseed, two_crops=True, cell=32)
+    bud = Budget(f"gpu_{name}_lazy{int(lazy)}")
+    anchor_y = g["anchor_y"] if "anchor_y" in g.files else None
+
+    def run(forced=None):
+        ts_ = build(b, cw, lazy=lazy, residual_gain=gain)
+        ts_.pixelcontrast_criterion.forced_anchors = forced
         s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
-        torch.manual_seed(321)
+        torch.manual_seed(rseed)
         out_ = ts_.step((s0, dict(left=img[b:])), do_optimizer_step=False)
         img_i, cls, pix, n_view = ts_.pixelcontrast_criterion.last_anchors
         same = np.array_equal(np.asarray(img_i), g["anchor_img"]) and \
             np.array_equal(pix.cpu().numpy().T.astype(np.int32), g["anchor_pix"])
-        return ts_, out_, same
+        return ts_, out_, same, np.asarray(cls, dtype=np.float32)
 
-    def forward_budgets(out_, tag):
-        bud.check(tag + "before", out_["left_seg_beforeup"], g["before"], g64["before"], metric=rel_max, e32=float(e32("before")))
-        bud.check(tag + "fine_feat", out_["fine_feat"][:, ::8], g["fine_feat_sub"], g64["fine_feat_sub"], metric=rel_max,
-                  e32=float(e32("fine_feat_sub")))
-        bud.check(tag + "seg logits", out_["left_seg"][:, :, ::4, ::4], g["seg_logits_sub"], g64["seg_logits_sub"],
-                  metric=rel_max, e32=float(e32("seg_logits_sub")))
-        _argmax_budget(bud, out_["left_seg"], g, g64)
-
-    ts, out, same = run()
-    forward_budgets(out, "")
-    bud.note("anchors", split_bf16_run_drew_the_reference_anchors=bool(same))
+    ts, out, same, cls = run()
+    outputs = (("before", out["left_seg_beforeup"][:, :, ::sb, ::sb], "before"),
+               ("fine_feat", out["fine_feat"][:, ::sfc, ::sfs, ::sfs], "fine_feat_sub"),
+               ("seg logits", out["left_seg"][:, :, ::sl, ::sl], "seg_logits_sub"))
+    for what, mine, key in outputs:
+        bud.check(what, mine, g[key], g64[key], metric=rel_max, e32=float(e32(key)))
+        if well:
+            bud.check_abs(what + " (north star 1e-3 vs the reference's fp32 result)", rel_max(mine, g[key]), 1e-3)
+    _argmax_budget(bud, out["left_seg"], g, g64, sl)
+    bud.note("anchors", free_run_drew_the_reference_anchors=bool(same))
     if not same:
-        monkeypatch.setenv("DCS_CONV_X3", "0")
-        ts, out, same = run()
-        assert same, "the exact-fp32 run must draw the very pixels the reference's sampler drew"
-        forward_budgets(out, "fp32 kernels: ")
-    # losses as in tests/step_check.py: held to the north-star tolerance (1e-3) against the float64 anchor, and the ratio
-    # to the reference's own fp32 error is recorded (one scalar is one draw of a heavy-tailed ratio: no K bound on it)
+        if anchor_y is None:                        # round-2 fixture: classes of the anchors = labels at their pixels
+            lab = torch.nn.functional.interpolate(labels.float().unsqueeze(1), (h // 4, w // 4), mode="nearest").long()
+            anchor_y = lab.reshape(b, -1)[torch.from_numpy(g["anchor_img"]).long(),
+                                          torch.from_numpy(g["anchor_pix"][:, 0]).long()].numpy().astype(np.float32)
+        del ts, out
+        ts, out, same, cls = run((g["anchor_img"], g["anchor_pix"], anchor_y))
+        assert same
+    if anchor_y is not None:
+        assert np.array_equal(cls, anchor_y)
+    # losses: north-star tolerance (1e-3) against the float64 anchor; the ratio to the reference's own fp32 error is
+    # recorded (one scalar is one draw of a heavy-tailed ratio: no K bound on it)
     for k in ("total", "supcon", "pixel", "seg"):
         err = abs(float(out[k].detach()) - float(g64[k])) / abs(float(g64[k]))
         bud.check_abs("loss " + k, err, 1e-3)
@@ -111,9 +135,13 @@ def test_deeplab_step_matches_reference_golden(golden_dir, lazy, monkeypatch):
     names = [str(s) for s in g["grad_names"]]
     e32n = e32("grad_norms")
     worst_n = float(e32n.max())                       # norms are single numbers: see step_check.run_and_check_step
+    worst_abs = 0.0
     for i, (k, n) in enumerate(zip(names, g["grad_norms"])):
-        bud.check("|grad| " + k, float(params[k].grad.double().norm()), float(n), float(g64["grad_norms"][i]), metric=rel_max,
-                  floor=worst_n)
+        gn = float(params[k].grad.double().norm())
+        bud.check("|grad| " + k, gn, float(n), float(g64["grad_norms"][i]), metric=rel_max, floor=worst_n)
+        worst_abs = max(worst_abs, abs(gn - float(g64["grad_norms"][i])) / max(float(g64["grad_norms"][i]), 1e-30))
+    if well:
+        bud.check_abs("worst gradient norm error (absolute bound 1e-2)", worst_abs, 1e-2)
     for key in g.files:
         if key.startswith("grad::"):
             gr = params[key[6:]].grad
@@ -152,27 +180,39 @@ def test_deeplab_eval_forward_matches_reference_golden(golden_dir):
 
 
 def test_deeplab_step_matches_oracle_and_trains(golden_dir):
-    """A second input (odd size 160x288) against the oracle.  The oracle's float64 run would sample other anchors here
-    (this model flips ~100 argmax pixels between fp32 and fp64), so the budget unit is borrowed from the golden fixture
-    of the same model and batch: K x the reference's float32 error measured there (tests/golden/deeplab_step_*.f64.npz)."""
-    g64 = np.load(os.path.join(golden_dir, "deeplab_step_b2_128x256.f64.npz"), allow_pickle=False)
+    """A second input (odd size 160x288) against the oracle, on the well-conditioned state (residual gain 0.25).  Two
+    fp32 evaluations are compared with each other: the north star's 1e-3 on features / logits, 1e-4 on the total loss and
+    1e-2 on the worst gradient norm, all in absolute terms (round 2: 17 % on the ill-conditioned state; the reference's
+    own fp32-vs-fp64 figures on this state are 2e-5 / 2e-3, tests/golden/deeplab_step_b4_256x512.f64.npz).  If the free run's sampler is redirected by an argmax near-tie, the oracle's anchors are injected."""
     b, h, w = 2, 160, 288
     img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=81, two_crops=True, cell=32)
-    ts = build(b, cw)
-    s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
-    torch.manual_seed(3)
-    out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
-    state, proj = D.make_state(seed=7), O.make_proj(seed=9, dim_in=2048)
+    state, proj = D.make_state(seed=7, residual_gain=0.25), O.make_proj(seed=9, dim_in=2048)
     ref, grads, _ = oracle_deeplab_step(state, proj, img, labels.clone(), ldw, weather, cw, b, 3)
+    a_img, a_pix, a_cls = ref["anchors"]
     bud = Budget("gpu_deeplab_oracle_160x288")
-    # two fp32 evaluations are compared with each other here: each may be e32 away from the truth
+
+    def run(forced=None):
+        ts_ = build(b, cw, residual_gain=0.25)
+        ts_.pixelcontrast_criterion.forced_anchors = forced
+        s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+        torch.manual_seed(3)
+        out_ = ts_.step((s0, dict(left=img[b:])), do_optimizer_step=False)
+        img_i, cls, pix, n_view = ts_.pixelcontrast_criterion.last_anchors
+        same = np.array_equal(np.asarray(img_i), a_img) and np.array_equal(pix.cpu().numpy().T, a_pix)
+        return ts_, out_, same
+
+    ts, out, same = run()
+    bud.note("anchors", free_run_drew_the_oracle_anchors=bool(same))
+    if not same:
+        ts, out, same = run((a_img, a_pix, a_cls))
+        assert same
     bud.check_abs("total", abs(float(out["total"].detach()) - float(ref["total"])) / abs(float(ref["total"])),
-                  2 * K * float(g64["e32::total"]))
-    bud.check_abs("fine_feat", rel(out["fine_feat"], ref["fine_feat"].numpy()), 2 * K * float(g64["e32::fine_feat_sub"]))
-    bud.check_abs("seg logits", rel(out["left_seg"], ref["seg_logits"].numpy()), 2 * K * float(g64["e32::seg_logits_sub"]))
+                  1e-4)
+    bud.check_abs("fine_feat", rel(out["fine_feat"], ref["fine_feat"].numpy()), 1e-3)
+    bud.check_abs("seg logits", rel(out["left_seg"], ref["seg_logits"].numpy()), 1e-3)
     params = dict(ts.model.named_parameters())
     worst = max(abs(float(params[k].grad.norm()) - float(gr.norm())) / max(float(gr.norm()), 1e-9) for k, gr in grads.items())
-    bud.check_abs("worst gradient norm", worst, 2 * K * float(g64["e32::grad_norms"].max()))
+    bud.check_abs("worst gradient norm", worst, 1e-2)
     bud.finish()
     losses = []
     ts.model._get_engine().dropout_noise = None            # device-side dropout mask from here on

@@ -19,14 +19,14 @@ def emu(monkeypatch):
     emu_ops.install(monkeypatch)
 
 
-def build(dt=torch.float32, flat=True, b=2, cw=None, lazy=False):
+def build(dt=torch.float32, flat=True, b=2, cw=None, lazy=False, residual_gain=1.0):
     from dcs_amd.trainer import TrainStep, make_opts
     opts = make_opts(criterion="supcon_pixelcontrast_focal", batch_size=b, deeplab=True, model="deeplabv3plus_resnet101",
                      dtype=dt, flat_params=flat, lazy_fine_feat0=lazy)
     ts = TrainStep(opts, class_weight=cw, device="cpu")
     if dt == torch.float64:
         ts.model.double(); ts.supcon_criterion.double(); ts.weather_clf.double()
-    state = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in D.make_state(seed=7).items()}
+    state = {k: (v.to(dt) if v.is_floating_point() else v.clone()) for k, v in D.make_state(seed=7, residual_gain=residual_gain).items()}
     ts.model.load_state_dict(state, strict=True)
     proj = [p.to(dt) for p in O.make_proj(seed=9, dim_in=2048)]
     with torch.no_grad():
@@ -58,6 +58,43 @@ def test_deeplab_step_matches_reference_golden(emu, golden_dir):
     for k, n in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
         gn = float(params[k].grad.norm())
         assert abs(gn - n) <= 1e-1 * max(n, 1e-6) + 1e-7, (k, gn, n)   # reference fp32 vs fp64: up to 4.2e-2
+
+
+@pytest.mark.parametrize("lazy", [False, True])
+def test_deeplab_step_matches_well_conditioned_golden_on_injected_anchors(emu, golden_dir, lazy):
+    """deeplab_step_b4_256x512 (8 crops of 256x512, residual gain 0.25): the reference's own fp32 run is 2e-5 (logits) /
+    2e-3 (worst gradient norm) from its float64 run, so the north-star 1e-3 on outputs and 1e-2 on every gradient norm
+    hold in absolute terms.  The anchors of the fixture are injected (PixelContrastLoss.forced_anchors): the loss and
+    gradient comparison must not depend on which way an argmax near-tie of the forward pass falls (the reference's own
+    channels_last run draws other pixels on this very fixture).  Both the materialised and the lazy fine_feat0."""
+    g = np.load(os.path.join(golden_dir, "deeplab_step_b4_256x512.npz"), allow_pickle=False)
+    b = 4
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, 256, 512, seed=53, two_crops=True, cell=32)
+    ts, _, _ = build(b=b, cw=cw, lazy=lazy, residual_gain=0.25)
+    ts.pixelcontrast_criterion.forced_anchors = (g["anchor_img"], g["anchor_pix"], g["anchor_y"])
+    s0 = dict(left=img[:b], label=labels.clone(), weather=weather, label_distance_weight=ldw)
+    torch.manual_seed(322)
+    out = ts.step((s0, dict(left=img[b:])), do_optimizer_step=False)
+    sb, sfc, sfs, s0c, s0s, sl = (int(v) for v in g["sub_strides"])
+    for k in ("total", "supcon", "pixel", "seg"):
+        assert abs(float(out[k].detach()) - float(g[k])) <= 1e-4 * abs(float(g[k])), (k, float(out[k].detach()), float(g[k]))
+    before = out["left_seg_beforeup"].detach().numpy()[:, :, ::sb, ::sb]
+    np.testing.assert_allclose(before, g["before"], rtol=0, atol=1e-3 * np.abs(g["before"]).max())
+    ff = out["fine_feat"].detach().numpy()[:, ::sfc, ::sfs, ::sfs]
+    np.testing.assert_allclose(ff, g["fine_feat_sub"], rtol=0, atol=1e-3 * np.abs(g["fine_feat_sub"]).max())
+    am = out["left_seg"].detach().argmax(1).numpy().astype(np.uint8)
+    assert int((am != g["seg_argmax"]).sum()) <= 36, int((am != g["seg_argmax"]).sum())   # reference fp32 vs fp64: 18
+    params = dict(ts.model.named_parameters())
+    worst = 0.0
+    for k, n in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
+        worst = max(worst, abs(float(params[k].grad.norm()) - n) / max(n, 1e-9))
+    assert worst <= 1e-2, worst
+    for key in g.files:
+        if key.startswith("grad::"):
+            gr = params[key[6:]].grad
+            mine = (gr if gr.numel() < 400000 else gr.flatten()[::37]).numpy()
+            err = np.linalg.norm((mine - g[key]).ravel()) / np.linalg.norm(g[key].ravel())
+            assert err <= 3e-2, (key, err)          # reference fp32 vs fp64 on these tensors: up to 9e-3
 
 
 def test_deeplab_engine_matches_oracle_fp64_odd_size(emu):

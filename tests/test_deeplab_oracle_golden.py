@@ -3,6 +3,7 @@ by running the reference's own model (tests/golden/make_golden_deeplab.py)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from oracle import deeplab_oracle as D
@@ -27,28 +28,43 @@ def oracle_deeplab_step(state, proj, img, labels, ldw, weather, cw, b, seed):
     torch.manual_seed(seed)
     seg, before, ff, ff0 = D.deeplab_forward(img, state, True, True)
     sup = O.supcon_loss(ff, pw, weather)
-    pix = O.pixel_contrast_loss(ff0, labels, before)
+    pix, sel = O.pixel_contrast_loss(ff0, labels, before, return_indices=True)
     segl = O.boundary_aware_focal_loss(seg, labels, ldw, cw)
     total = 1 / b * (sup + pix) + segl * 1.2
     g = torch.autograd.grad(total, [state[k] for k in names] + pw, allow_unused=True)
     for k in names:
         state[k].requires_grad_(False)
     out = dict(total=total.detach(), supcon=sup.detach(), pixel=pix.detach(), seg=segl.detach(), before=before.detach(),
-               fine_feat=ff.detach(), fine_feat0=ff0.detach(), seg_logits=seg.detach())
+               fine_feat=ff.detach(), fine_feat0=ff0.detach(), seg_logits=seg.detach(),
+               anchors=(sel[0].numpy(), sel[2].numpy(), sel[1].numpy().astype(np.float32)))     # img [T], pix [T, n_view], cls [T]
     return out, dict(zip(names, g[:len(names)])), list(g[len(names):])
 
 
-def test_deeplab_train_step_matches_reference(golden_dir):
-    g = load(golden_dir, "deeplab_step_b2_128x256.npz")
-    state = D.make_state(seed=7)
+# name -> (batch, height, width, data seed, generator seed, residual gain): tests/golden/make_golden_deeplab.py::FIXTURES
+STEP_FIXTURES = {
+    "deeplab_step_b2_128x256": (2, 128, 256, 51, 321, 1.0),
+    "deeplab_step_b4_256x512": (4, 256, 512, 53, 322, 0.25),
+}
+
+
+def sub_strides(g):
+    return tuple(int(v) for v in g["sub_strides"]) if "sub_strides" in g.files else (1, 8, 1, 16, 2, 4)
+
+
+@pytest.mark.parametrize("name", list(STEP_FIXTURES))
+def test_deeplab_train_step_matches_reference(golden_dir, name):
+    g = load(golden_dir, name + ".npz")
+    b, h, w, dseed, rseed, gain = STEP_FIXTURES[name]
+    state = D.make_state(seed=7, residual_gain=gain)
     proj = O.make_proj(seed=9, dim_in=2048)
-    img, labels, ldw, weather, cw = O.synthetic_batch(2, 128, 256, seed=51, two_crops=True, cell=32)
-    out, grads, gproj = oracle_deeplab_step(state, proj, img, labels.clone(), ldw, weather, cw, 2, 321)
+    img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=dseed, two_crops=True, cell=32)
+    out, grads, gproj = oracle_deeplab_step(state, proj, img, labels.clone(), ldw, weather, cw, b, rseed)
+    sb, sfc, sfs, s0c, s0s, sl = sub_strides(g)
     for k in ("total", "supcon", "pixel", "seg"):
         close(out[k], g[k])
-    close(out["before"], g["before"])
-    close(out["fine_feat"][:, ::8], g["fine_feat_sub"])
-    close(out["fine_feat0"][:, ::16, ::2, ::2], g["fine_feat0_sub"])
+    close(out["before"][:, :, ::sb, ::sb], g["before"])
+    close(out["fine_feat"][:, ::sfc, ::sfs, ::sfs], g["fine_feat_sub"])
+    close(out["fine_feat0"][:, ::s0c, ::s0s, ::s0s], g["fine_feat0_sub"])
     assert np.array_equal(out["seg_logits"].argmax(1).numpy().astype(np.uint8), g["seg_argmax"])
     for k, n in zip([str(s) for s in g["grad_names"]], g["grad_norms"]):
         gn = float(grads[k].norm())

@@ -4,7 +4,9 @@ A: with eval-mode BatchNorm the model is per-image independent, so the DP step (
 B: training mode with per-rank anchor sampling: ranks agree on the global losses and end with identical
    parameters; the global pixel loss equals the oracle's loss on the union of both ranks' anchors.
 C: SimCLR image contrast (class_labels=None): instance ids stay unique across ranks -- DP == single process.
-D: one rank's shard is all "ignore": it joins the collectives with padding only (no hang), zero pixel gradient."""
+D: one rank's shard is all "ignore": it joins the collectives with padding only (no hang), zero pixel gradient.
+E/F: BASELINE config 5's model (DeepLabV3+ / ResNet-101) under the same wrapper: E as A, F as B with the lazy 2048-channel
+   fine_feat0 (rows interpolated on demand before the gather)."""
 import pytest
 import torch
 
@@ -47,3 +49,14 @@ def test_dp_simclr_instance_labels_are_unique_across_ranks(dp_results, monkeypat
 
 def test_dp_rank_without_anchors_joins_the_collectives(dp_results):
     check_empty_rank(*dp_results)
+
+
+def test_deeplab_dp_equals_single_process_with_eval_batchnorm(dp_results, monkeypatch):
+    emu_ops.install(monkeypatch)
+    ts, out = single_process("supcon_focal", 49, "cpu", deeplab=True)
+    check_equals_single_process(dp_results[0], dp_results[1], "E", ts, out, loss_rtol=1e-4)
+
+
+def test_deeplab_dp_training_mode_global_losses_and_sync(dp_results):
+    check_training_mode(*dp_results, prefix="F", images_per_rank=2)
+    assert dp_results[0]["F_pixel_rows"].shape[1] == 2048

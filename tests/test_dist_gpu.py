@@ -1,6 +1,9 @@
-"""GPU: rehearsal of the multi-rank bench path on ONE GPU (two ranks share cuda:0, gloo backend; the real job uses
-RCCL with one rank per GPU): device-tensor all-gather of contrastive rows, flat-bucket gradient all-reduce, one JSON
-line from rank 0."""
+"""GPU: what ONE GPU allows of the multi-rank path.
+  * two ranks sharing cuda:0 over GLOO (a single card cannot host two RCCL ranks): the bench rehearsal and the numeric
+    DP checks on the real kernels (SwiftNet and DeepLabV3+);
+  * the REAL backend (RCCL, "nccl") at world size 1 (tests/rccl_worker.py): librccl loads, every collective of
+    dcs_amd/dist.py runs on device memory, DP step == plain step for both models.
+No RCCL run with N > 1 exists in this repository: that is the driver's 8-GPU scaling bench."""
 import json
 import os
 import subprocess
@@ -59,3 +62,41 @@ def test_two_rank_dp_global_pixel_loss_on_real_kernels(dp_gpu_results):
     from dist_checks import check_empty_rank, check_training_mode
     check_training_mode(*dp_gpu_results)
     check_empty_rank(*dp_gpu_results)
+
+
+def test_two_rank_deeplab_dp_on_real_kernels(dp_gpu_results):
+    """BASELINE config 5's model under DataParallelStep on the real kernels (two gloo ranks on one GPU): eval-mode
+    BatchNorm => equals the single-process step; training mode with the lazy 2048-channel fine_feat0 => ranks agree bit
+    for bit, global pixel loss equals the oracle on the union of the 2048-wide anchor rows."""
+    from dist_checks import check_equals_single_process, check_training_mode, single_process
+    r0, r1 = dp_gpu_results
+    ts, out = single_process("supcon_focal", 49, "cuda:0", deeplab=True)
+    check_equals_single_process(r0, r1, "E", ts, out, loss_rtol=1e-5, grad_rtol=2e-3)
+    check_training_mode(r0, r1, prefix="F", images_per_rank=2)
+
+
+def test_rccl_backend_world_size_one():
+    """The production backend itself: one rank, backend "nccl" (= RCCL), launched like the driver launches bench.py."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "tests", "rccl_worker.py")]
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    line = [l for l in p.stdout.decode().splitlines() if l.startswith("RCCL_WORKER ")][0]
+    rec = json.loads(line[len("RCCL_WORKER "):])
+    out = os.path.join(ROOT, "gpurun_out", "parity")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "rccl_world1.json"), "w") as f:
+        json.dump(rec, f, indent=1)
+    assert rec["backend"] == "nccl" and rec["world"] == 1
+    assert any("rccl" in l for l in rec["mapped_libraries"]) and any("libdcs_hip" in l for l in rec["mapped_libraries"])
+    assert rec["row_gather_ok"] and rec["flat_allreduce_ok"]
+    assert abs(rec["seg_reduce"][0] - 2.5) < 1e-6 and rec["seg_reduce"][1] == 1000.0
+    for st in rec["steps"]:
+        # equal to rounding, not bitwise: the DP path pads the anchor rows to the gather capacity (other block
+        # partition of the similarity kernel) and renormalises the seg loss by the all-reduced count (x * N * (1 / N))
+        assert st["same_anchors"], st
+        assert st["loss_rel_err"] <= 2e-6, st
+        assert st["grad_rel_l2_max"] <= 1e-4 and st["param_rel_l2_max"] <= 1e-4, st

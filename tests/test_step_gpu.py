@@ -116,7 +116,7 @@ def _oracle_step(dt, criterion, b, img, labels, ldw, weather, cw, seed, mkldnn=T
 @pytest.mark.parametrize("criterion,two,b,h,w,seed", [
     ("supcon_focal", True, 2, 224, 352, 170), ("supcon_simclr_pixelcontrast_focal", True, 2, 256, 288, 172),
     ("supcon_crossentropy", True, 2, 200, 320, 172), ("focal", False, 3, 232, 416, 73),
-    ("supcon_simclr_cross_entropy", True, 2, 256, 384, 171)])
+    ("supcon_simclr_cross_entropy", True, 2, 256, 384, 171), ("supcon_simclr_focal", True, 2, 240, 368, 175)])
 def test_train_step_matches_oracle(monkeypatch, criterion, two, b, h, w, seed, ksplit):
     """Criteria without a reference golden: the oracle (pinned to the reference by the goldens) is evaluated here in
     float32 (two execution paths) AND float64; the HIP step is held to K x the oracle's own fp32-vs-fp64 error, split-K
@@ -124,7 +124,7 @@ def test_train_step_matches_oracle(monkeypatch, criterion, two, b, h, w, seed, k
     pre-activation is within fp32 noise of zero, and any two float32 evaluations -- the oracle's own two paths included
     -- then differ by 10x .. 100x on the gradients behind it (tests/budget.py).  The seeds used here are ones on which
     a third independent float32 evaluation (the CPU emulation of the kernels, tests/emu_ops.py) agrees with the oracle's
-    paths, i.e. inputs on which 'the float32 result' is a meaningful notion."""
+    paths, i.e. inputs on which 'the float32 result' is a meaningful notion (tools/seed_scan.py)."""
     monkeypatch.setenv("DCS_KSPLIT", ksplit)
     img, labels, ldw, weather, cw = O.synthetic_batch(b, h, w, seed=seed, two_crops=two, cell=32)
     ts = build(criterion, batch_size=b, cw=cw)
