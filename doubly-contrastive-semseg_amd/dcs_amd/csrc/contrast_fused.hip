@@ -435,8 +435,6 @@ struct StripParams {
   float* slab;                         // [nchunk][A][C] dX partials (phase 4)
   float* gsym; int ldg;                // phase 4 with C > 128: Gsym written out instead
   const float* av;                     // [1] number of valid rows
-  int dbg;                             // diagnostics (DCS_CONTRAST_DBG): 1 = skip the MFMAs, 2 = skip the epilogues,
-                                       // 4 = stop after pass 1 (similarity product + statistics: bench.py times it)
 };
 
 // C/D layout of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
@@ -629,7 +627,6 @@ void contrast_strip_kernel(const StripParams p) {
       if (kc + 1 < nkc) load_j(J, kc + 1, true);
       else { load_j(J + 1, 0, J + 1 < jend); load_aux(J + 1, J + 1 < jend); }                // prefetch
       __syncthreads();
-      if (p.dbg & 1) continue;
       // phases 1-3: acc[r] = S[i = strip row 32 wm + row32(r,h)][j = tile row 32 wn + lane]
       // phase 4:    acc[r] = S[t = tile row 32 wm + row32(r,h)][q = strip row 32 wn + lane]
       const float* bj = &(PHASE == 4 ? XI : XJ)[(32 * wn + l31) * XLDL + 4 * h];
@@ -645,7 +642,6 @@ void contrast_strip_kernel(const StripParams p) {
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
       }
     }
-    if (p.dbg & 2) continue;
     // ---- epilogue: lane holds S[i = 32 wm + row32(r, h)][j = 32 wn + l31], r = 0..15 (phase 4: [t][q]) ----
     const int jl = 32 * wn + l31, jg = J * TB + jl;
     const bool diag = J == I;
@@ -943,7 +939,6 @@ int launch_large(const float* X, int ldx, const float* y, int ldy, const float* 
   StripParams p;
   p.X = X; p.ldx = ldx; p.y = y; p.ldy = ldy; p.mask = mask; p.mb = mb; p.A = A; p.C = C; p.mode = mode; p.ntile = ntile;
   p.it = it; p.rnorm = rnorm; p.rec = rec; p.P = P; p.slab = slab; p.gsym = gsym; p.ldg = ldg; p.av = av;
-  { const char* e = getenv("DCS_CONTRAST_DBG"); p.dbg = e ? atoi(e) : 0; }
   // statistics sweeps: ~3 blocks per CU.  chunks per strip I = ceil((ntile - I) / CH)
   int CH = 1;
   for (; CH < 16; ++CH) {
@@ -972,7 +967,6 @@ int launch_large(const float* X, int ldx, const float* y, int ldy, const float* 
       !set_attr(reinterpret_cast<const void*>(contrast_strip_kernel<3, 1>), strip_smem(3))) return DCS_E_LAUNCH;
   LAUNCH_STRIP(1, dim3((unsigned)nb_stats), dim3(256), strip_smem(1), s, p);
   hipLaunchKernelGGL(contrast_combine_kernel<1>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
-  if (p.dbg & 4) { DCS_LAUNCH_RET(); }      // timing of the similarity pass alone (results are not a loss)
   LAUNCH_STRIP(2, dim3((unsigned)nb_stats), dim3(256), strip_smem(2), s, p);
   hipLaunchKernelGGL(contrast_combine_kernel<2>, cg, dim3(256), 0, s, P, y, ldy, rnorm, av, A, ntile, CH, mode, rec, loss_row);
   if (mode == 0) {

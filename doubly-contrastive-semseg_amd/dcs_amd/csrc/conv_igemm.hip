@@ -796,7 +796,7 @@ bool wgrad3x3_eligible(const DcsConvGeom* g) {
 // K-chunk policy: 64-wide output tiles (64-channel layers, 1x1 skip convs) run the 16-channel chunk variant
 // (32.5 KB LDS -> 4 blocks per CU; measured +4 % on 3x3 64->64 and +27 % on the bandwidth-bound 1x1 64->128);
 // 128-wide tiles measure the same either way and keep 32-channel chunks.  DCS_CONV_BK16 forces 16 everywhere.
-static const bool g_bk16 = getenv("DCS_CONV_BK16") != nullptr;
+#define g_bk16 (dcs_config().conv_bk16 != 0)
 // Measured and dropped: 256-pixel tiles (the BM template parameter; identical TFLOP/s on every C3
 // shape, so the loss against peak is not per-tile overhead but MFMA-busy 78-89 % at a 2.0-2.35 GHz DVFS clock) and a
 // 3x3 kernel with the 6x34-pixel input halo resident in LDS (3-5 % slower than this per-tap kernel).
@@ -895,7 +895,7 @@ extern "C" int dcs_conv_gather_split(const float* src, const float* wgt, float* 
 
 // 128-wide generic weight-gradient tiles stage 16 pixels per chunk (32 KB LDS, 4 blocks per CU): +4..9 % over 32-pixel
 // chunks at 2 blocks per CU on the 1x1 layers (the kernel is stall-bound, not MFMA-bound).  DCS_WGRAD_CH32 restores 32.
-static const bool g_wgrad_ch16 = getenv("DCS_WGRAD_CH32") == nullptr;
+#define g_wgrad_ch16 (dcs_config().wgrad_ch32 == 0)
 
 static int launch_wgrad(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride, int split0,
                         int nsplit, void* stream, const float* pro);

@@ -1620,7 +1620,7 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
   const int bn_ = geom->Cout > 64 ? 128 : 64;
   const int ntiles = (geom->Cout + bn_ - 1) / bn_;
   // 64-wide layers of large maps: 256-pixel tiles (enough of them to fill the chip several times over)
-  const bool bm256 = bn_ == 64 && nsplit == 1 && M >= 256ll * 2048 && getenv("DCS_X3_BM128") == nullptr;
+  const bool bm256 = bn_ == 64 && nsplit == 1 && M >= 256ll * 2048 && dcs_config().x3_bm128 == 0;
   const long long blocks = (bm256 ? (M + 255) / 256 : (M + 127) / 128) * ntiles;
   DCS_CHECK_ARG(blocks > 0 && blocks * nsplit < (1ll << 30));
   const int nch = geom->ntaps * (geom->stem ? 1 : geom->K >> 4);
@@ -1634,9 +1634,8 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
   P.nbx = (unsigned)blocks;
   P.nby = (unsigned)nsplit;
   // DCS_X3_HALO=0: never; =2: whenever the geometry allows (tests: small shapes); default: when there are enough tiles
-  const char* halo_env = getenv("DCS_X3_HALO");                  // read per launch: the tests flip it
-  const bool g_halo = halo_env == nullptr || halo_env[0] != '0';
-  const bool g_halo_force = halo_env != nullptr && halo_env[0] == '2';
+  const bool g_halo = dcs_config().x3_halo != 0;
+  const bool g_halo_force = dcs_config().x3_halo == 2;
   if (g_halo && nsplit == 1 && (long long)geom->SH * geom->SW * geom->src_cstride * 4 <= 0x7FFFFFFFll) {
     // enough tiles to fill the chip twice over, else the per-tap kernel (and its K splits) does better
     if (bn_ == 64 && conv3x3_halo_eligible(geom, 8) && (g_halo_force || M >= 256ll * 1024)) {
@@ -1830,8 +1829,7 @@ int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
       if (imgs > geom->N) imgs = geom->N;
       const long long xbytes = imgs * geom->SH * geom->SW * geom->src_cstride * 4;
       const long long dbytes = imgs * geom->TY * geom->TX * dy_cstride * 4;
-      const char* roll = getenv("DCS_WGRAD_ROLL");
-      if ((roll == nullptr || roll[0] != '0') && xbytes < 0x7FFFFFFFll && dbytes < 0x7FFFFFFFll) {
+      if (dcs_config().wgrad_roll != 0 && xbytes < 0x7FFFFFFFll && dbytes < 0x7FFFFFFFll) {
         P.kid = WK_ROLL;
         return DCS_OK;
       }

@@ -46,12 +46,11 @@ __device__ __forceinline__ float4 ld4s(const float* p, const bool nt) { return n
 __device__ __forceinline__ void st4s(float* p, const float4 v, const bool nt) {
   if (nt) stx4<true>(p, v); else stx4<false>(p, v);
 }
-// does a tensor of this many bytes stream?  (DCS_BN_NT=0: never -- A/B switch)
+#include "dcs_config.h"
+// does a tensor of this many bytes stream?
 static inline bool dcs_streams(long long bytes) {
-  const char* e = getenv("DCS_BN_NT");
-  const char* m = getenv("DCS_NT_MIN_MB");          // threshold: C3 steps are flat (+-0.5 ms) between 64 and 512 MiB
-  const long long min_mb = m ? atoll(m) : 256;
-  return bytes >= (min_mb << 20) && !(e && e[0] == '0');
+  const DcsConfig& c = dcs_config();
+  return c.bn_nt != 0 && bytes >= ((long long)c.nt_min_mb << 20);
 }
 
 __device__ __forceinline__ float dcs_wave_sum(float v) {

@@ -47,6 +47,8 @@ _G = C.POINTER(DcsConvGeom)
 
 # name -> argtypes (all return int); mirrors include/dcs_hip.h one to one
 SIGNATURES = {
+    "dcs_set_option": [C.c_char_p, _I],
+    "dcs_get_option": [C.c_char_p, C.POINTER(C.c_int)],
     "dcs_conv_gather": [_P, _P, _P, _P, _G, _I, _P, _P],
     "dcs_conv_gather_bnbwd": [_P, _P, _P, _G, _I, _P, _P, _P, _I, _P, _P],
     "dcs_conv_gather_split": [_P, _P, _P, C.POINTER(DcsConvGeom), _I, _L, _P],
@@ -136,3 +138,18 @@ def load():
 def check(rc: int, name: str):
     if rc != 0:
         raise RuntimeError(f"{name} failed: {ERRORS.get(rc, rc)}")
+
+
+def set_option(name: str, value: int) -> int:
+    """Change a library switch (include/dcs_hip.h: dcs_set_option); returns the previous value."""
+    lib = load()
+    old = C.c_int(0)
+    check(lib.dcs_get_option(name.encode(), C.byref(old)), "dcs_get_option")
+    check(lib.dcs_set_option(name.encode(), int(value)), "dcs_set_option")
+    return old.value
+
+
+def get_option(name: str) -> int:
+    v = C.c_int(0)
+    check(load().dcs_get_option(name.encode(), C.byref(v)), "dcs_get_option")
+    return v.value

@@ -29,6 +29,14 @@ extern "C" {
 
 #define DCS_MAX_TAPS 49
 
+/* ---- library switches -------------------------------------------------------------------------
+ * A/B and test switches of the kernels (no reference counterpart).  Their initial values are read from the environment
+ * ONCE, when the library is loaded (DCS_BN_NT, DCS_NT_MIN_MB, DCS_X3_BM128, DCS_X3_HALO, DCS_WGRAD_ROLL, DCS_CONV_BK16,
+ * DCS_WGRAD_CH32); no launcher reads the environment.  Names: "bn_nt", "nt_min_mb", "x3_bm128", "x3_halo", "wgrad_roll",
+ * "conv_bk16", "wgrad_ch32" (csrc/dcs_config.h says what each one does).  Not thread-safe against concurrent launches. */
+int dcs_set_option(const char* name, int value);
+int dcs_get_option(const char* name, int* value);
+
 /* Gather geometry shared by forward conv, data-gradient and weight-gradient kernels.
  * The GEMM row index m enumerates a sub-grid (n, ty, tx), ty < TY, tx < TX of the DESTINATION
  * tensor: dest pixel = (ty*dsy + dy0, tx*dsx + dx0).  For tap t the SOURCE pixel is

@@ -19,3 +19,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture()
+def libopt(monkeypatch):
+    """Set a switch of libdcs_hip.so for one test: the library reads its DCS_* environment variables once at load time, so
+    a test changes them through dcs_set_option (and mirrors the value into the environment for the Python-side readers of
+    the same name); restored afterwards."""
+    from dcs_amd import lib
+    saved = {}
+
+    def set_(name, value):
+        old = lib.set_option(name, int(value))
+        saved.setdefault(name, old)
+        monkeypatch.setenv("DCS_" + name.upper(), str(value))
+    yield set_
+    for name, old in saved.items():
+        lib.set_option(name, old)

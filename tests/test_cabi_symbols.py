@@ -44,6 +44,26 @@ def test_argument_errors_are_reported_not_crashed():
         lib.check(-1, "x")
 
 
+def test_library_switches_are_set_through_the_abi_not_the_environment(monkeypatch):
+    """The launchers never read the environment: the DCS_* variables are read once at load time and tests / tools flip a
+    switch through dcs_set_option.  Unknown names are argument errors."""
+    from dcs_amd import lib
+    l = lib.load()
+    assert lib.get_option("bn_nt") in (0, 1) and lib.get_option("nt_min_mb") > 0
+    old = lib.set_option("x3_halo", 2)
+    try:
+        monkeypatch.setenv("DCS_X3_HALO", "0")                 # changing the environment after load has no effect
+        assert lib.get_option("x3_halo") == 2
+    finally:
+        lib.set_option("x3_halo", old)
+    assert lib.get_option("x3_halo") == old
+    assert l.dcs_set_option(b"no_such_switch", 1) == -1 and l.dcs_set_option(None, 1) == -1
+    src = os.path.join(ROOT, "doubly-contrastive-semseg_amd", "dcs_amd", "csrc")
+    for f in os.listdir(src):
+        if f.endswith((".hip", ".h")):
+            assert "getenv" not in open(os.path.join(src, f)).read(), f
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     from dcs_amd import lib
     monkeypatch.setattr(lib, "_lib", None)

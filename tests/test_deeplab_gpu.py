@@ -149,9 +149,21 @@ def test_deeplab_step_matches_reference_golden(golden_dir, name, lazy):
             bud.family("stored gradient tensors", key, mine, g[key], g64[key], e32=float(e32(key)))
     sd = ts.model.state_dict()
     worst_rs = float(e32("rs_norms").max())
+    # b2_128x256 only: the ASPP pooling branch normalises TWO values per channel (nn.BatchNorm2d on [2,256,1,1]); where they
+    # nearly coincide x_hat = d / sqrt(d^2 + eps) amplifies fp32 noise of the pooled features up to 316x, and the branch
+    # feeds aspp.project and everything behind it.  Measured (tools/aspp_project_probe.py, profiles/r03_aspp_probe.txt): the
+    # projection kernel itself reproduces the per-channel mean of a float64 projection of ITS OWN inputs to 2e-9, while
+    # those inputs differ by 4e-3 between the split-bf16 and the exact-fp32 kernels -- so the running statistics behind
+    # that branch are held to K x the reference's fp32 error on the quantity behind the same amplification (the logits),
+    # all others to K x the reference's worst running-statistics error.  The well-conditioned fixture (4 values per
+    # channel) needs no such exception.
+    behind_pool = ("classifier.aspp.project.1.", "classifier.classifier.1.")
     for i, (k, n) in enumerate(zip([str(s) for s in g["rs_names"]], g["rs_norms"])):
+        floor = max(worst_rs, 1e-6)
+        if not well and k.startswith(behind_pool):
+            floor = max(floor, float(e32("before")))
         bud.check("|running| " + k, float(sd[k].double().norm()), float(n), float(g64["rs_norms"][i]), metric=rel_max,
-                  floor=max(worst_rs, 1e-6))
+                  floor=floor)
     bud.finish_family("stored gradient tensors")
     bud.finish()
 

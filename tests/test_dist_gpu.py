@@ -95,8 +95,8 @@ def test_rccl_backend_world_size_one():
     assert rec["row_gather_ok"] and rec["flat_allreduce_ok"]
     assert abs(rec["seg_reduce"][0] - 2.5) < 1e-6 and rec["seg_reduce"][1] == 1000.0
     for st in rec["steps"]:
-        # equal to rounding, not bitwise: the DP path pads the anchor rows to the gather capacity (other block
-        # partition of the similarity kernel) and renormalises the seg loss by the all-reduced count (x * N * (1 / N))
+        # bitwise the plain step: padding rows of the fixed-shape gather take part in nothing, x * N * (1 / N) of the
+        # seg-loss renormalisation and the world-1 sum all-reduce happen to be exact here (measured: 87 / 338 gradient
+        # tensors bitwise); kernels are deterministic, so this does not flake
         assert st["same_anchors"], st
-        assert st["loss_rel_err"] <= 2e-6, st
-        assert st["grad_rel_l2_max"] <= 1e-4 and st["param_rel_l2_max"] <= 1e-4, st
+        assert st["loss_rel_err"] == 0.0 and st["grads_bitwise"] == st["grad_tensors"] and st["param_rel_l2_max"] == 0.0, st

@@ -723,7 +723,7 @@ def test_split_bf16_weight_gradient_has_fp32_class_error(ops, monkeypatch, N, H,
     (2, 16, 64, 64, 64), (1, 8, 32, 64, 64), (3, 24, 32, 48, 64), (2, 16, 64, 64, 48),      # 8 x 32-pixel tiles, 64 channels wide
     (16, 16, 64, 128, 128), (8, 12, 96, 256, 128), (8, 8, 64, 128, 256),                    # 4 x 32-pixel tiles, 128 wide
 ])
-def test_split_bf16_convolution_with_resident_halo(ops, monkeypatch, N, H, W, Cin, Cout):
+def test_split_bf16_convolution_with_resident_halo(ops, monkeypatch, libopt, N, H, W, Cin, Cout):
     """conv3x3_x3_kernel (input halo resident in LDS, nine taps per staged chunk) forced on small maps (DCS_X3_HALO=2)
     against the per-tap split-bf16 kernel (DCS_X3_HALO=0) and float64: forward with statistics, BatchNorm + ReLU prologue
     (bitwise equal to the materialised activation), data gradient accumulating into a tensor with the BatchNorm-backward
@@ -741,7 +741,7 @@ def test_split_bf16_convolution_with_resident_halo(ops, monkeypatch, N, H, W, Ci
     wp = ops.pack_dgrad_weight(wd)
     res = {}
     for mode in ("2", "0"):
-        monkeypatch.setenv("DCS_X3_HALO", mode)
+        libopt("x3_halo", mode)
         y, st = ops.conv_fwd(xd, wd, 1, 1, want_stats=True)
         y2, st2 = ops.conv_fwd(xd, wd, 1, 1, want_stats=True)
         assert torch.equal(y, y2) and torch.equal(st, st2)
@@ -759,14 +759,14 @@ def test_split_bf16_convolution_with_resident_halo(ops, monkeypatch, N, H, W, Ci
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(4, 16, 64, 128, 128), (2, 8, 32, 256, 128), (1, 12, 96, 128, 256), (2, 16, 64, 64, 64)])
-def test_halo_kernel_with_weight_fragments_from_global_memory(ops, monkeypatch, N, H, W, Cin, Cout):
+def test_halo_kernel_with_weight_fragments_from_global_memory(ops, monkeypatch, libopt, N, H, W, Cin, Cout):
     """dcs_conv3x3_x3w (weight fragments straight from global memory in dcs_split_weight_frag layout, no per-tap barrier)
     performs exactly the arithmetic of conv3x3_x3_kernel: outputs, batch statistics, prologue and the data gradient with
     BatchNorm-backward sums must be BITWISE those of the LDS-staged halo kernel (DCS_X3_HALO=2 forces it on small maps)."""
     import ctypes as C
     from dcs_amd.ops import _p, _call, _stream
     monkeypatch.setenv("DCS_KSPLIT", "0")
-    monkeypatch.setenv("DCS_X3_HALO", "2")
+    libopt("x3_halo", 2)
     x = rnd(N, H, W, Cin, seed=131).to(DEV)
     w = cl(rnd(Cout, Cin, 3, 3, seed=132, scale=0.05).to(DEV))
     gam, bet = (rnd(Cin, seed=133) * 0.1 + 1).to(DEV), (rnd(Cin, seed=134) * 0.1).to(DEV)
@@ -892,7 +892,7 @@ def test_level_batched_stem_is_bitwise_the_per_level_stem(ops, monkeypatch):
         assert torch.equal(a, b)
 
 
-def test_streaming_access_paths_are_bitwise_the_default_paths(ops, monkeypatch):
+def test_streaming_access_paths_are_bitwise_the_default_paths(ops, monkeypatch, libopt):
     """Tensors of >= 256 MiB go through non-temporal loads / stores (dcs_common.h: dcs_streams) in the single-pass kernels
     and in the convolution epilogue.  The arithmetic is the same, only the cache policy differs: with the threshold forced
     to 0 (every tensor streams) each operation must return BITWISE what it returns with streaming off -- and the default
@@ -934,10 +934,10 @@ def test_streaming_access_paths_are_bitwise_the_default_paths(ops, monkeypatch):
         return [t.clone() for t in out if t is not None]
 
     monkeypatch.setenv("DCS_KSPLIT", "0")          # keep the fused BatchNorm-backward epilogue on this small map
-    monkeypatch.setenv("DCS_BN_NT", "0")
+    libopt("bn_nt", 0)
     ref = run()
-    monkeypatch.setenv("DCS_BN_NT", "1")
-    monkeypatch.setenv("DCS_NT_MIN_MB", "0")
+    libopt("bn_nt", 1)
+    libopt("nt_min_mb", 0)
     got = run()
     assert len(ref) == len(got) >= 17
     for i, (a, b) in enumerate(zip(ref, got)):
