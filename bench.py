@@ -11,10 +11,13 @@ Workload at N=1 = BASELINE.json configs[2] ("C3"): B=16 labelled images (32 crop
 2048x1024, criterion supcon_pixelcontrast_focal -- the configuration the metric is quoted on; it fits one GPU.
 Weak scaling: every rank keeps B=16.
 
-roofline: dominant kernel = the implicit-GEMM conv kernel (forward + data gradient launches, conv_gather_kernel,
-EVERY launch: plain and split-K).
-achieved = algorithmic FLOPs (2*M*taps*K*Cout per launch) / summed launch time measured with HIP
-events recorded on the launch stream during the timed steps.  peak = 157.3 TFLOP/s (fp32 MFMA, MI355X_MICROARCH.md).
+roofline: dominant kernel family = the implicit-GEMM gather launches (conv forward + data gradient; every launch: plain,
+split-K, fused prologue / epilogue, level-batched).  achieved = algorithmic fp32 FLOPs (2*M*taps*K*Cout per launch,
+SURVEY.md 8(d)) / summed launch time measured with HIP events recorded on the launch stream during the timed steps.
+peak = 416.7 TFLOP/s fp32-equivalent when most of those FLOPs ran on the split-bf16 kernels (dense bf16 MFMA peak 2500 / 6
+piece products per fp32 product, MI355X_MICROARCH.md), else the 157.3 TFLOP/s of the fp32 MFMA; the fraction of the fp32
+MFMA peak is reported next to it.  roofline.hbm_family: the HBM-bound rest of the step (BatchNorm, pooling, resizes, fused
+seg loss ...) as algorithmic bytes / HIP-event time against 8 TB/s, measured in two extra steps after the timed region.
 cpu_baseline: the oracle (pure-PyTorch CPU restatement, kind "port") on a bounded sample of the same workload.
 """
 import argparse
@@ -53,6 +56,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-similarity", action="store_true", help="skip the similarity-kernel measurement after the timed "
                     "region (profiling runs: keeps the per-kernel averages to the train step's own launches)")
+    ap.add_argument("--no-hbm-family", action="store_true", help="skip the two instrumented extra steps that measure the "
+                    "HBM-bound operations (roofline.hbm_family)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--conv-report", default=None, help="write a per-shape conv timing table (json lines) to this file")
     return ap.parse_args()
@@ -216,6 +221,33 @@ def pmc_traffic(args, world):
         return json.load(f)["conv_gather"]["hbm_bytes_per_launch"]
 
 
+def hbm_family_pass(ops, one_step, steps=2):
+    """The HBM-bound part of the step (everything that is not matrix-core work): every dcs_amd.ops call bracketed by a
+    HIP event pair, algorithmic bytes = each distinct tensor argument / result once (tools/op_report.py), in `steps`
+    extra steps AFTER the timed region, level batching off so that a launch leaves the library inside the call that is
+    being timed (the HBM-bound kernels run per pyramid level either way)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from op_report import OpProfiler
+    old = os.environ.get("DCS_LEVEL_BATCH")
+    os.environ["DCS_LEVEL_BATCH"] = "0"
+    prof = OpProfiler(ops)
+    try:
+        one_step()                                  # allocator / caches settle in the per-level launch order
+        torch.cuda.synchronize()
+        prof.enabled = True
+        for _ in range(steps):
+            one_step()
+        torch.cuda.synchronize()
+        prof.enabled = False
+        return prof.hbm_family(steps)
+    finally:
+        prof.restore()
+        if old is None:
+            del os.environ["DCS_LEVEL_BATCH"]
+        else:
+            os.environ["DCS_LEVEL_BATCH"] = old
+
+
 def similarity_bench(ops, dev, ts, reps=20):
     """BASELINE.json's second metric: TFLOP/s of the pixel-contrastive similarity / InfoNCE loss, forward AND backward
     (utils/loss.py:339-389), outside the timed region, HIP events.  Algorithmic FLOPs = 2 A^2 d (S = X X^T) +
@@ -244,28 +276,9 @@ def similarity_bench(ops, dev, ts, reps=20):
             us = ev[0].elapsed_time(ev[1]) / reps * 1e3
             res[name + "_fwd_bwd_us"] = us
             res[name + "_tflops"] = 6.0 * A * A * 128 / us / 1e6
-        if A > 1024:            # the strip kernels: time pass 1 alone = the similarity product S = X X^T + its statistics
-            os.environ["DCS_CONTRAST_DBG"] = "4"        # (the library stops after that pass; the outputs are not a loss)
-            try:
-                for _ in range(3):
-                    ops.contrast_fwd_bwd(X, y, 0, 0.07)
-                ev[0].record()
-                for _ in range(reps):
-                    ops.contrast_fwd_bwd(X, y, 0, 0.07)
-                ev[1].record()
-                torch.cuda.synchronize()
-            finally:
-                del os.environ["DCS_CONTRAST_DBG"]
-            us = ev[0].elapsed_time(ev[1]) / reps * 1e3
-            res["similarity_pass_us"] = us
-            res["similarity_pass_tflops"] = 2.0 * A * A * 128 / us / 1e6      # algorithmic 2 A^2 d of S = X X^T
-            res["similarity_pass_note"] = ("prep + strip pass 1 + combine: S = X X^T with row/column statistics; only the "
-                                           "upper-triangular 64x64 tiles are computed (executed FLOPs = half)")
         out[tag] = res
     gl = out["global"]
     out["similarity_kernel_frac_global"] = gl["loss_tflops"] / PEAK_FP32_MFMA_TFLOPS     # whole fused loss at the C4 size
-    if "similarity_pass_tflops" in gl:
-        out["similarity_pass_frac_global"] = gl["similarity_pass_tflops"] / PEAK_FP32_MFMA_TFLOPS
     out["note"] = "rank size (A <= 608): 95 MFLOP = 0.6 us at peak, i.e. launch-latency bound: two launches"
     return out
 
@@ -397,6 +410,8 @@ def main():
                        **({"lazy_fine_feat0": bool(args.lazy_ff0)} if deeplab else {})},
             "roofline": roofline(g, wg, args, world),
         }
+        if world == 1 and not args.no_hbm_family:           # (extra steps: rank 0 alone cannot run them in a DP job)
+            line["roofline"]["hbm_family"] = hbm_family_pass(ops, one_step)
         if not args.no_similarity:
             line["similarity"] = similarity_bench(ops, dev, ts)
         if args.conv_report:
