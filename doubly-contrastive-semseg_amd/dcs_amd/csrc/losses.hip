@@ -79,43 +79,50 @@ void seg_loss_kernel(const float* __restrict__ logits, int64_t* __restrict__ tar
 // utils/loss.py:41-42, :60-73): the full-resolution logits [N,C,H,W] (2.55 GB at C3) and their gradient are never
 // materialised.  Input = the low-resolution NHWC logits [N,ih,iw,cs]; output = d(sum loss)/d(low-res logits) in the
 // same layout, i.e. the adjoint of the bilinear upsampling applied on the fly.  H = F*ih, W = F*iw, F in {2, 4}.
+// Interpolation weights: lin_src, the very weights (and association) of upsample_to_nchw_kernel.  Exponentials are
+// v_exp_f32 of x * log2(e) (arguments are <= 0 after the max shift, relative error <= 1e-6).
 //
-// Block = one tile of TH x TW = 8 x 32 low-resolution pixels of one image.
-//   stage: the tile's logits + a 1-pixel halo -> LDS.
-//   phase A, one output pixel at a time over the tile's F*TH x F*TW owned pixels and the F/2-pixel ring around them
-//     (pixels whose bilinear taps touch the tile): interpolate the C logits (lin_src: the very weights of
-//     upsample_to_nchw_kernel), log-sum-exp, loss coefficient -> LDS (lse, coef, target: 9 bytes per pixel); owned
-//     pixels add to the loss / count and get the in-place 255 -> 0 label rewrite (utils/loss.py:43).
-//   phase B, one thread per low-resolution pixel: GATHER its gradient from the <= (2F)^2 output pixels of its footprint
-//     (p_c re-evaluated from the staged logits: 4x redundant exp work, in exchange for a fixed summation order: no float
-//     atomics, bitwise reproducible).  Exponentials are v_exp_f32 of x * log2(e) (__expf: arguments are <= 0 after the
-//     max / log-sum-exp shift, relative error <= 1e-6): with the library expf the kernel is instruction-bound (3.8 ms at
-//     C3 instead of ~1 ms).
-constexpr int SLF_TH = 8, SLF_TW = 32;
+// Round 3 -- the CELL form (seg_loss_cells_kernel).  The first fused kernel (round 2: one pass per output pixel for the
+// log-sum-exp, then a gather per low-resolution pixel that re-evaluated the 19-class softmax of every output pixel of its
+// footprint: 5 softmax evaluations per output pixel, all operands through LDS) was instruction-bound at 2.9 ms for C3 (3 % of
+// the HBM roof).  With align_corners=False and an integer factor F the F x F outputs {F k + F/2 .. F k + F/2 + F - 1}^2 share
+// their four bilinear taps: the low-resolution pixels (k, k+1) x (k', k'+1) -- a CELL.  One thread owns one cell: per cell
+// column it forms the x-interpolated top / bottom rows once, per output pixel it interpolates in y, evaluates ONE softmax
+// in registers, and folds the gradient coef (p - onehot) back onto the cell's four corners with the same separable
+// weights (rows first, then columns).  A low-resolution pixel is a corner of four cells: the per-corner sums go through
+// LDS once and every pixel adds its <= 9 terms in fixed order (bitwise reproducible, no float atomics).  A block owns
+// 7 x 31 low-resolution pixels and evaluates the 8 x 32 cells that touch them (cells -1 .. 6 relative to the tile: 15 %
+// redundant cell work at tile borders instead of a second kernel or atomics); loss, count and the in-place 255 -> 0 label
+// rewrite (utils/loss.py:43) belong to the one block that OWNS the cell.
+constexpr int SLC_CH = 8, SLC_CW = 32;                    // cells per block = threads
+constexpr int SLC_PH = SLC_CH - 1, SLC_PW = SLC_CW - 1;   // low-resolution pixels owned per block
 
 template <int F, int MAXC>
-__global__ __launch_bounds__(256)
-void seg_loss_fused_kernel(const float* __restrict__ lr, const int cs, int64_t* __restrict__ target,
+__global__ __launch_bounds__(SLC_CH * SLC_CW, 2)
+void seg_loss_cells_kernel(const float* __restrict__ lr, const int cs, int64_t* __restrict__ target,
                            const float* __restrict__ ldw, const float* __restrict__ cw, float* __restrict__ glr,
                            float* __restrict__ partial, const int C, const int ih, const int iw, const int mode,
                            const float gamma, const int ignore, const int tiles_x, const int tiles_y) {
-  constexpr int LH = SLF_TH + 2, LW = SLF_TW + 2;                 // staged low-res rows / cols (1-pixel halo)
-  constexpr int RH = F * SLF_TH + F, RW = F * SLF_TW + F;         // phase-A region (owned + F/2 ring)
-  constexpr int LP = MAXC + 1;                                    // odd pixel stride in LDS: conflict-free tap reads
+  constexpr int NT = SLC_CH * SLC_CW;
+  constexpr int LH = SLC_CH + 1, LW = SLC_CW + 1;                 // staged low-res pixels: the corners of the block's cells
+  constexpr int LP = 21;                                          // odd pixel stride (>= MAXC): conflict-free reads across cells
+  constexpr int BS = 43;                                          // odd per-cell stride of the corner-sum exchange buffer
+  constexpr int NOPIX = (int)0x80000000;                          // "no such output pixel"
+  static_assert(MAXC <= 20, "LP / BS are sized for <= 20 classes");
+  constexpr float LOG2E_ = 1.4426950408889634f;
   __shared__ float tile[LH * LW * LP];
-  __shared__ float s_lse[RH * RW], s_coef[RH * RW];
-  __shared__ signed char s_t[RH * RW];
-  __shared__ double s_red[2][4];
+  __shared__ float xch[NT * BS];
+  __shared__ double s_red[2][NT / 64];
   const int tid = threadIdx.x;
   int b = blockIdx.x;
   const int tx = b % tiles_x; b /= tiles_x;
   const int ty = b % tiles_y;
   const int n = b / tiles_y;
-  const int iy0 = ty * SLF_TH, ix0 = tx * SLF_TW;
+  const int iy0 = ty * SLC_PH, ix0 = tx * SLC_PW;
   const int H = F * ih, W = F * iw;
-  const float sc = 1.f / (float)F;                                // = ih / H: the scale lin_src expects
-  // ---- stage the low-res tile (rows iy0-1 .. iy0+TH, clamped reads; clamped duplicates are never used with weight)
-  for (int e = tid; e < LH * LW; e += 256) {
+  const float sc = 1.f / (float)F;
+  // ---- stage: tile row ly / column lx = low-res pixel clamp(iy0 - 1 + ly), clamp(ix0 - 1 + lx)
+  for (int e = tid; e < LH * LW; e += NT) {
     const int ly = e / LW, lx = e - ly * LW;
     int gy = iy0 - 1 + ly, gx = ix0 - 1 + lx;
     gy = gy < 0 ? 0 : (gy > ih - 1 ? ih - 1 : gy);
@@ -125,114 +132,150 @@ void seg_loss_fused_kernel(const float* __restrict__ lr, const int cs, int64_t* 
     for (int c = 0; c < MAXC; ++c) tile[e * LP + c] = c < C ? src[c] : 0.f;
   }
   __syncthreads();
-  // ---- phase A
-  const int oy0 = F * iy0 - F / 2, ox0 = F * ix0 - F / 2;         // region origin (may be negative)
+  // ---- the thread's cell: ky = iy0 - 1 + cy, kx = ix0 - 1 + cx; its corners are tile rows cy, cy + 1 / columns cx, cx + 1
+  const int cy = tid / SLC_CW, cx = tid - cy * SLC_CW;
+  const int ky = iy0 - 1 + cy, kx = ix0 - 1 + cx;
+  const bool cell_ok = ky <= ih - 1 && kx <= iw - 1;
+  const bool owned = cell_ok && (cy >= 1 || iy0 == 0) && (cx >= 1 || ix0 == 0);
+  const int oyb = F * ky + F / 2, oxb = F * kx + F / 2;           // first output row / column of the cell (may be < 0)
+  float acc[2][2][MAXC];                                          // [corner row][corner column][class]
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) { acc[0][0][c] = 0.f; acc[0][1][c] = 0.f; acc[1][0][c] = 0.f; acc[1][1][c] = 0.f; }
   double lsum = 0.0, lcnt = 0.0;
-  for (int e = tid; e < RH * RW; e += 256) {
-    const int ry = e / RW, rx = e - ry * RW;
-    const int oy = oy0 + ry, ox = ox0 + rx;
-    float lse = 0.f, coef = 0.f;
-    int tt = 0;
-    if (oy >= 0 && oy < H && ox >= 0 && ox < W) {
-      const Lin ly = lin_src(oy, sc, ih), lx = lin_src(ox, sc, iw);
-      const float* p00 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
-      const float* p01 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
-      const float* p10 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
-      const float* p11 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
-      const long long pix = ((long long)n * H + oy) * W + ox;
-      long long t = target[pix];
-      const bool owned = ry >= F / 2 && ry < F / 2 + F * SLF_TH && rx >= F / 2 && rx < F / 2 + F * SLF_TW;
-      bool counted;
-      float a = 1.f;
-      if (mode == 4) {
-        counted = t != ignore;
-        if (!counted || t < 0 || t >= C) t = 0;
-      } else {
-        if (t == ignore) { t = 0; if (owned) target[pix] = 0; }    // utils/loss.py:43 (in place)
-        if (t < 0 || t >= C) t = 0;
-        a = ldw[pix];
-        counted = a > 0.f;
+  if (cell_ok) {
+    // labels / boundary weights of the cell's F x F outputs: all loads in flight before the arithmetic starts
+    int tg[F][F];
+    float aw[F][F];
+#pragma unroll
+    for (int ry = 0; ry < F; ++ry) {
+      const int oy = oyb + ry;
+      const bool rok = oy >= 0 && oy < H;
+      const long long rowp = ((long long)n * H + (rok ? oy : 0)) * W;
+#pragma unroll
+      for (int rx = 0; rx < F; ++rx) {
+        const int ox = oxb + rx;
+        const bool ok = rok && ox >= 0 && ox < W;
+        tg[ry][rx] = ok ? (int)target[rowp + ox] : NOPIX;
+        aw[ry][rx] = (ok && mode != 4) ? ldw[rowp + ox] : 0.f;
       }
-      float v[MAXC], mx = -INFINITY, xt = 0.f;
+    }
+    const float* t00 = &tile[(cy * LW + cx) * LP];
+    const float* t01 = t00 + LP;
+    const float* t10 = t00 + LW * LP;
+    const float* t11 = t10 + LP;
+#pragma unroll
+    for (int rx = 0; rx < F; ++rx) {
+      const int ox = oxb + rx;
+      if (ox < 0 || ox >= W) continue;
+      const Lin lx = lin_src(ox, sc, iw);
+      float top[MAXC], bot[MAXC], a0[MAXC], a1[MAXC];
 #pragma unroll
       for (int c = 0; c < MAXC; ++c) {
-        if (c < C) {
-          // same association as upsample_to_nchw_kernel: x first, then y
-          const float top = fmaf(lx.w1, p01[c], lx.w0 * p00[c]);
-          const float bot = fmaf(lx.w1, p11[c], lx.w0 * p10[c]);
-          v[c] = fmaf(ly.w1, bot, ly.w0 * top);
-        } else v[c] = -INFINITY;
-        mx = fmaxf(mx, v[c]);
-        if (c == (int)t) xt = v[c];
+        // same association as upsample_to_nchw_kernel: x first, then y
+        top[c] = fmaf(lx.w1, t01[c], lx.w0 * t00[c]);
+        bot[c] = fmaf(lx.w1, t11[c], lx.w0 * t10[c]);
+        a0[c] = 0.f; a1[c] = 0.f;
       }
-      float se = 0.f;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) se += c < C ? __expf(v[c] - mx) : 0.f;
-      lse = mx + logf(se);
-      const float logpt = xt - lse;
-      if (mode == 4) coef = counted ? 1.f : 0.f;
-      else {
-        const float pt = __expf(logpt);
-        const float mod = __expf(gamma * (1.f - pt));
-        const float w = cw ? cw[t] : 1.f;
-        coef = mode == 0 ? w * a * mod : (mode == 1 ? mod : (mode == 2 ? a * mod : w * mod));
-      }
-      if (owned) { lsum += (double)(-coef * logpt); lcnt += counted ? 1.0 : 0.0; }
-      tt = (int)t;
-    }
-    s_lse[e] = lse; s_coef[e] = coef; s_t[e] = (signed char)tt;
-  }
-  __syncthreads();
-  // ---- phase B: thread = low-res pixel (ly_, lx_) of the tile
-  {
-    const int ly_ = tid / SLF_TW, lx_ = tid - ly_ * SLF_TW;
-    const int iy = iy0 + ly_, ix = ix0 + lx_;
-    if (iy < ih && ix < iw) {
-      float acc[MAXC];
-#pragma unroll
-      for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
-      // footprint: outputs whose taps include this pixel: [F*i - F/2 - (F-1)... ] conservatively [F*i - F, F*i + 2F) clipped
-      const int ylo = F * iy - F < 0 ? 0 : F * iy - F, yhi = F * iy + 2 * F - 1 > H - 1 ? H - 1 : F * iy + 2 * F - 1;
-      const int xlo = F * ix - F < 0 ? 0 : F * ix - F, xhi = F * ix + 2 * F - 1 > W - 1 ? W - 1 : F * ix + 2 * F - 1;
-      for (int oy = ylo; oy <= yhi; ++oy) {
+      for (int ry = 0; ry < F; ++ry) {
+        int t = tg[ry][rx];
+        if (t == NOPIX) continue;
+        const int oy = oyb + ry;
         const Lin ly = lin_src(oy, sc, ih);
-        const float wy = (ly.i0 == iy ? ly.w0 : 0.f) + (ly.i1 == iy ? ly.w1 : 0.f);
-        if (wy == 0.f) continue;
-        const int ry = oy - oy0;
-        if (ry < 0 || ry >= RH) continue;                          // cannot happen for wy != 0; keeps LDS reads in range
-        for (int ox = xlo; ox <= xhi; ++ox) {
-          const Lin lx = lin_src(ox, sc, iw);
-          const float wx = (lx.i0 == ix ? lx.w0 : 0.f) + (lx.i1 == ix ? lx.w1 : 0.f);
-          if (wx == 0.f) continue;
-          const int rx = ox - ox0;
-          if (rx < 0 || rx >= RW) continue;
-          const int e = ry * RW + rx;
-          const float coef = s_coef[e];
-          if (coef == 0.f) continue;
-          const float lse = s_lse[e];
-          const int t = s_t[e];
-          const float* p00 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
-          const float* p01 = &tile[((ly.i0 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
-          const float* p10 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i0 - ix0 + 1)) * LP];
-          const float* p11 = &tile[((ly.i1 - iy0 + 1) * LW + (lx.i1 - ix0 + 1)) * LP];
-          const float wc = wy * wx * coef;
+        const float a = aw[ry][rx];
+        bool counted;
+        if (mode == 4) {
+          counted = t != ignore;
+          if (!counted || t < 0 || t >= C) t = 0;
+        } else {
+          if (t == ignore) { t = 0; if (owned) target[((long long)n * H + oy) * W + ox] = 0; }   // utils/loss.py:43 (in place)
+          if (t < 0 || t >= C) t = 0;
+          counted = a > 0.f;
+        }
+        float v[MAXC], mx = -INFINITY, xt = 0.f;
 #pragma unroll
-          for (int c = 0; c < MAXC; ++c) {
-            if (c < C) {
-              const float top = fmaf(lx.w1, p01[c], lx.w0 * p00[c]);
-              const float bot = fmaf(lx.w1, p11[c], lx.w0 * p10[c]);
-              const float vc = fmaf(ly.w1, bot, ly.w0 * top);
-              // d(-coef logpt)/dv_c = coef (p_c - [c == t])   (pt is detached: loss.py:63)
-              acc[c] = fmaf(wc, __expf(vc - lse) - (c == t ? 1.f : 0.f), acc[c]);
-            }
-          }
+        for (int c = 0; c < MAXC; ++c) {
+          v[c] = c < C ? fmaf(ly.w1, bot[c], ly.w0 * top[c]) : -INFINITY;
+          mx = fmaxf(mx, v[c]);
+          xt = c == t ? v[c] : xt;
+        }
+        const float mb = -mx * LOG2E_;
+        float se = 0.f;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) { v[c] = c < C ? __builtin_amdgcn_exp2f(fmaf(v[c], LOG2E_, mb)) : 0.f; se += v[c]; }
+        const float logpt = xt - (mx + logf(se));
+        float coef;
+        if (mode == 4) coef = counted ? 1.f : 0.f;
+        else {
+          const float pt = __expf(logpt);
+          const float mod = __expf(gamma * (1.f - pt));
+          const float w = cw ? cw[t] : 1.f;
+          coef = mode == 0 ? w * a * mod : (mode == 1 ? mod : (mode == 2 ? a * mod : w * mod));
+        }
+        if (owned) { lsum += (double)(-coef * logpt); lcnt += counted ? 1.0 : 0.0; }
+        // d(-coef logpt)/dv_c = coef (p_c - [c == t])   (pt is detached: loss.py:63); rows first
+        const float cp = coef / se;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c) {
+          const float g = fmaf(v[c], cp, c == t ? -coef : 0.f);
+          a0[c] = fmaf(ly.w0, g, a0[c]);
+          a1[c] = fmaf(ly.w1, g, a1[c]);
         }
       }
-      float* dst = glr + (((long long)n * ih + iy) * iw + ix) * cs;
 #pragma unroll
-      for (int c = 0; c < MAXC; ++c) if (c < cs) dst[c] = c < C ? acc[c] : 0.f;
-      for (int c = MAXC; c < cs; ++c) dst[c] = 0.f;
+      for (int c = 0; c < MAXC; ++c) {
+        acc[0][0][c] = fmaf(lx.w0, a0[c], acc[0][0][c]); acc[0][1][c] = fmaf(lx.w1, a0[c], acc[0][1][c]);
+        acc[1][0][c] = fmaf(lx.w0, a1[c], acc[1][0][c]); acc[1][1][c] = fmaf(lx.w1, a1[c], acc[1][1][c]);
+      }
     }
+  }
+  // ---- corner sums -> low-resolution pixels.  Thread = owned pixel (py, px); pixel p is corner 1 of cell p - 1 and corner 0
+  // of cell p; clamped borders add corner 0 of cell -1 to pixel 0 and corner 1 of cell in - 1 to pixel in - 1.
+  const int py = tid / SLC_PW, px = tid - py * SLC_PW;
+  const int iy = iy0 + py, ix = ix0 + px;
+  const bool pix_ok = tid < SLC_PH * SLC_PW && iy < ih && ix < iw;
+  float gs[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) gs[c] = 0.f;
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {                                   // corner row r of every cell, both corner columns
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { xch[tid * BS + c] = acc[r][0][c]; xch[tid * BS + 21 + c] = acc[r][1][c]; }
+    __syncthreads();
+    if (pix_ok) {
+      // cell rows whose corner row r is this pixel row: r == 1 -> cell py (ky = iy - 1), r == 0 -> cell py + 1 (ky = iy);
+      // border: iy == 0 also takes corner row 0 of cell py (ky = -1); iy == ih - 1 also corner row 1 of cell py + 1
+      int cys[2], ncy = 0;
+      if (r == 1) { cys[ncy++] = py; if (iy == ih - 1) cys[ncy++] = py + 1; }
+      else { if (iy == 0) cys[ncy++] = py; cys[ncy++] = py + 1; }
+      for (int a = 0; a < ncy; ++a) {
+        const int cyy = cys[a];
+        if (iy0 - 1 + cyy > ih - 1) continue;                     // no such cell
+        // columns: corner column 1 of cell px, corner column 0 of cell px + 1 (+ the clamped borders)
+        const float* rowb = &xch[(cyy * SLC_CW) * BS];
+        if (ix == 0) { const float* q = rowb + px * BS;
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) gs[c] += q[c]; }
+        { const float* q = rowb + px * BS + 21;
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) gs[c] += q[c]; }
+        if (ix0 - 1 + px + 1 <= iw - 1) {
+          const float* q = rowb + (px + 1) * BS;
+#pragma unroll
+          for (int c = 0; c < MAXC; ++c) gs[c] += q[c];
+          if (ix == iw - 1) { const float* q1 = q + 21;
+#pragma unroll
+            for (int c = 0; c < MAXC; ++c) gs[c] += q1[c]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (pix_ok) {
+    float* dst = glr + (((long long)n * ih + iy) * iw + ix) * cs;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) if (c < cs) dst[c] = c < C ? gs[c] : 0.f;
+    for (int c = MAXC; c < cs; ++c) dst[c] = 0.f;
   }
   // ---- block reduction of the loss / count
   lsum = dcs_wave_sum_d(lsum); lcnt = dcs_wave_sum_d(lcnt);
@@ -603,18 +646,23 @@ extern "C" int dcs_seg_loss_fused(const float* logits_lr, int cs, int64_t* targe
   DCS_CHECK_ARG(mode >= 0 && mode <= 4 && (mode == 4 || ldw));
   if (H <= 0 || W <= 0 || H % ih != 0 || W % iw != 0 || H / ih != W / iw) return DCS_E_UNSUPPORTED;
   const int F = H / ih;
-  const int tiles_x = (iw + SLF_TW - 1) / SLF_TW, tiles_y = (ih + SLF_TH - 1) / SLF_TH;
+  const int tiles_x = (iw + SLC_PW - 1) / SLC_PW, tiles_y = (ih + SLC_PH - 1) / SLC_PH;
   DCS_CHECK_ARG((long long)N * tiles_x * tiles_y == blocks);
   hipStream_t s = dcs_stream(stream);
-  if (F == 4)
-    hipLaunchKernelGGL((seg_loss_fused_kernel<4, 20>), dim3((unsigned)blocks), dim3(256), 0, s, logits_lr, cs, target, ldw, cw,
-                       grad_lr, partial, C, ih, iw, mode, gamma, ignore, tiles_x, tiles_y);
-  else if (F == 2)
-    hipLaunchKernelGGL((seg_loss_fused_kernel<2, 20>), dim3((unsigned)blocks), dim3(256), 0, s, logits_lr, cs, target, ldw, cw,
-                       grad_lr, partial, C, ih, iw, mode, gamma, ignore, tiles_x, tiles_y);
-  else
-    return DCS_E_UNSUPPORTED;
+#define DCS_SLC(F_, MC_)                                                                                                  \
+  hipLaunchKernelGGL((seg_loss_cells_kernel<F_, MC_>), dim3((unsigned)blocks), dim3(SLC_CH * SLC_CW), 0, s, logits_lr, cs, \
+                     target, ldw, cw, grad_lr, partial, C, ih, iw, mode, gamma, ignore, tiles_x, tiles_y)
+  if (F == 4) { if (C <= 19) DCS_SLC(4, 19); else DCS_SLC(4, 20); }
+  else if (F == 2) { if (C <= 19) DCS_SLC(2, 19); else DCS_SLC(2, 20); }
+  else return DCS_E_UNSUPPORTED;
+#undef DCS_SLC
   DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_seg_loss_fused_blocks(int N, int ih, int iw) {
+  if (N <= 0 || ih <= 0 || iw <= 0) return DCS_E_ARG;
+  const long long nb = (long long)N * ((iw + SLC_PW - 1) / SLC_PW) * ((ih + SLC_PH - 1) / SLC_PH);
+  return nb < (1ll << 30) ? (int)nb : DCS_E_UNSUPPORTED;
 }
 
 extern "C" int dcs_seg_loss_final(const float* partial, float* out, int blocks, void* stream) {

@@ -85,6 +85,7 @@ SIGNATURES = {
     "dcs_upsample_to_nchw_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_seg_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],
     "dcs_seg_loss_fused": [_P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _I, _I, _P],
+    "dcs_seg_loss_fused_blocks": [_I, _I, _I],
     "dcs_seg_loss_final": [_P, _P, _I, _P],
     "dcs_scale_inplace": [_P, _L, _P, _P, _P],
     "dcs_anchor_keys": [_P, _I, _I, _P, _I, _I, _I, _I, _I, _I, _P, _P, _I, _P],

@@ -939,7 +939,9 @@ def seg_loss_fused(logits_lr, Cc, target, ldw, cw, mode, gamma=0.5, ignore=255):
     N, ih, iw, cs = logits_lr.shape
     H, W = target.shape[1:]
     grad = torch.empty_like(logits_lr)
-    blocks = N * (-(-ih // 8)) * (-(-iw // 32))
+    blocks = _lib.load().dcs_seg_loss_fused_blocks(N, ih, iw)
+    if blocks <= 0:
+        _lib.check(blocks, "dcs_seg_loss_fused_blocks")
     part = torch.empty((blocks, 2), device=logits_lr.device, dtype=_F32)
     out = torch.empty((3,), device=logits_lr.device, dtype=_F32)
     _call("dcs_seg_loss_fused", _p(logits_lr), cs, _p(target), _p(ldw), _p(cw), _p(grad), _p(part), N, Cc, ih, iw, H, W,

@@ -264,12 +264,14 @@ int dcs_upsample_to_nchw_bwd(const float* g, const float* gscale, float* gx, flo
  * logits_lr [N,ih,iw,cs] low-resolution NHWC logits (C <= 20 <= cs used); target / ldw at the full resolution
  * H = F*ih, W = F*iw (F in {2,4}, else DCS_E_UNSUPPORTED: use dcs_upsample_to_nchw + dcs_seg_loss).  The bilinear
  * upsampling (align_corners=False) is evaluated on the fly with the weights of dcs_upsample_to_nchw; grad_lr
- * [N,ih,iw,cs] = d(sum loss)/d(logits_lr) (the adjoint of the upsampling gathered per low-resolution pixel, fixed
- * order); partial [blocks][2], blocks = N * ceil(ih/8) * ceil(iw/32), -> dcs_seg_loss_final.  Modes as dcs_seg_loss;
- * target is rewritten in place (255 -> 0) unless mode == 4. */
+ * [N,ih,iw,cs] = d(sum loss)/d(logits_lr) (the adjoint of the upsampling: per-cell corner sums added per low-resolution
+ * pixel in fixed order); partial [blocks][2], blocks = dcs_seg_loss_fused_blocks(N, ih, iw), -> dcs_seg_loss_final.
+ * Modes as dcs_seg_loss; target is rewritten in place (255 -> 0) unless mode == 4. */
 int dcs_seg_loss_fused(const float* logits_lr, int cs, int64_t* target, const float* ldw, const float* cw,
                        float* grad_lr, float* partial, int N, int C, int ih, int iw, int H, int W, int mode, float gamma,
                        int ignore, int blocks, void* stream);
+/* number of blocks (= rows of `partial`) of dcs_seg_loss_fused for this geometry (> 0), or a negative DCS_E_* code */
+int dcs_seg_loss_fused_blocks(int N, int ih, int iw);
 /* ---- segmentation losses (utils/loss.py:39-80; nn.CrossEntropyLoss) --------------------------
  * logits NCHW [N,C,H,W]; target int64 [N,H,W]; ldw [N,H,W]; cw [C].
  * mode 0: boundary-aware focal (w*alpha), 1: plain_focal, 2: no_class_weights, 3: no_EDT,
