@@ -709,35 +709,55 @@ void stem_wgrad_kernel(const float* __restrict__ src, const float* __restrict__ 
   }
 }
 
-// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i].  Block = 64 columns x 4 split lanes: each lane sums splits
+// dw[i] = (accumulate ? dw[i] : 0) + sum_s slab[s][i].  Block = 64 column groups x 4 split lanes: each lane sums splits
 // sl, sl+4, ... with independent loads in flight, then the 4 partial sums are added in fixed order (deterministic).
+// V = columns per thread: 4 (16-byte loads; n, row_len and dst_stride multiples of 4) or 1.
+template <int V>
 __global__ __launch_bounds__(256)
 void reduce_slab_kernel(const float* __restrict__ slab, float* __restrict__ dw, long long n, int nsplit,
                         int accumulate, int row_len, int dst_stride) {
-  __shared__ double sm[4][64];
+  __shared__ double sm[4][64][V];
   const int c = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const long long i = (long long)blockIdx.x * 64 + c;
-  double s = 0.0;                      // double accumulators: up to 1024 slabs of mixed sign per element, HBM-bound kernel
+  const long long i = ((long long)blockIdx.x * 64 + c) * V;
+  double s[V];                         // double accumulators: up to 1024 slabs of mixed sign per element, HBM-bound kernel
+#pragma unroll
+  for (int v = 0; v < V; ++v) s[v] = 0.0;
   if (i < n) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    double a[4][V];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int v = 0; v < V; ++v) a[q][v] = 0.0;
+    auto add = [&](int q, int k) {
+      const float* p = slab + (long long)k * n + i;
+      if constexpr (V == 4) {
+        const float4 x = *reinterpret_cast<const float4*>(p);
+        a[q][0] += (double)x.x; a[q][1] += (double)x.y; a[q][2] += (double)x.z; a[q][3] += (double)x.w;
+      } else {
+        a[q][0] += (double)p[0];
+      }
+    };
     int k = sl;
-    for (; k + 12 < nsplit; k += 16) {
-      s0 += (double)slab[(long long)k * n + i];
-      s1 += (double)slab[(long long)(k + 4) * n + i];
-      s2 += (double)slab[(long long)(k + 8) * n + i];
-      s3 += (double)slab[(long long)(k + 12) * n + i];
-    }
-    for (; k < nsplit; k += 4) s0 += (double)slab[(long long)k * n + i];
-    s = (s0 + s1) + (s2 + s3);
+    for (; k + 12 < nsplit; k += 16) { add(0, k); add(1, k + 4); add(2, k + 8); add(3, k + 12); }
+    for (; k < nsplit; k += 4) add(0, k);
+#pragma unroll
+    for (int v = 0; v < V; ++v) s[v] = (a[0][v] + a[1][v]) + (a[2][v] + a[3][v]);
   }
-  sm[sl][c] = s;
+#pragma unroll
+  for (int v = 0; v < V; ++v) sm[sl][c][v] = s[v];
   __syncthreads();
   if (sl == 0 && i < n) {
-    const double t = ((sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]));
     // row_len > 0: the slab holds compact rows of row_len floats that land at stride dst_stride in dw
     // (a channel slice of a wider weight tensor, used for "virtual concat" convolutions)
     const long long o = row_len > 0 ? (i / row_len) * dst_stride + (i % row_len) : i;
-    dw[o] = (float)((accumulate ? (double)dw[o] : 0.0) + t);
+    float r[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+      const double t = ((sm[0][c][v] + sm[1][c][v]) + (sm[2][c][v] + sm[3][c][v]));
+      r[v] = (float)((accumulate ? (double)dw[o + v] : 0.0) + t);
+    }
+    if constexpr (V == 4) *reinterpret_cast<float4*>(dw + o) = make_float4(r[0], r[1], r[2], r[3]);
+    else dw[o] = r[0];
   }
 }
 
@@ -966,8 +986,13 @@ static int launch_wgrad(const float* src, const float* dy, float* slab, const Dc
 extern "C" int dcs_reduce_slab(const float* slab, float* dw, int64_t n, int nsplit, int accumulate, int row_len,
                                int dst_stride, void* stream) {
   DCS_CHECK_ARG(slab && dw && n > 0 && nsplit > 0 && row_len >= 0 && (row_len == 0 || (dst_stride >= row_len && n % row_len == 0)));
-  hipLaunchKernelGGL(reduce_slab_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, dcs_stream(stream), slab, dw,
-                     (long long)n, nsplit, accumulate, row_len, dst_stride);
+  const bool v4 = (n & 3) == 0 && (row_len & 3) == 0 && (dst_stride & 3) == 0 && dcs_aligned16(slab) && dcs_aligned16(dw);
+  if (v4)
+    hipLaunchKernelGGL(reduce_slab_kernel<4>, dim3((unsigned)((n / 4 + 63) / 64)), dim3(256), 0, dcs_stream(stream), slab, dw,
+                       (long long)n, nsplit, accumulate, row_len, dst_stride);
+  else
+    hipLaunchKernelGGL(reduce_slab_kernel<1>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, dcs_stream(stream), slab, dw,
+                       (long long)n, nsplit, accumulate, row_len, dst_stride);
   DCS_LAUNCH_RET();
 }
 

@@ -116,6 +116,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
     constexpr bool PRE = NP <= 8;
 #endif
     float4 pre_o[PRE ? NP : 1], pre_y[PRE ? NP : 1], pre_m[PRE ? NP : 1];
+#if defined(DCS_SLP_EXP) && DCS_SLP_EXP == 2
+#pragma unroll
+    for (int p = 0; p < (PRE ? NP : 1); ++p) { pre_o[p] = zero4(); pre_y[p] = zero4(); pre_m[p] = zero4(); }
+#endif
     const bool vrow = vec_ok && colv + 3 < Cout;
     if (PRE && vrow && (acc_dst || do_bnb)) {
 #pragma unroll
@@ -152,6 +156,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
           b_s0.x += gm.x; b_s0.y += gm.y; b_s0.z += gm.z; b_s0.w += gm.w;
           b_s1.x = fmaf(gm.x, (yy.x - b_mu.x) * b_is.x, b_s1.x); b_s1.y = fmaf(gm.y, (yy.y - b_mu.y) * b_is.y, b_s1.y);
           b_s1.z = fmaf(gm.z, (yy.z - b_mu.z) * b_is.z, b_s1.z); b_s1.w = fmaf(gm.w, (yy.w - b_mu.w) * b_is.w, b_s1.w);
+#if defined(DCS_SLP_EXP) && DCS_SLP_EXP == 1
+          asm volatile("" : "+v"(b_s0.x), "+v"(b_s0.y), "+v"(b_s0.z), "+v"(b_s0.w));
+          asm volatile("" : "+v"(b_s1.x), "+v"(b_s1.y), "+v"(b_s1.z), "+v"(b_s1.w));
+#endif
         }
       } else {
         const float vv[4] = {v.x, v.y, v.z, v.w};
@@ -170,7 +178,12 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
 #pragma unroll
       for (int o = EPV; o < 64; o <<= 1)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) vals[e] += __shfl_xor(vals[e], o, 64);
+        for (int e = 0; e < 8; ++e) {
+          vals[e] += __shfl_xor(vals[e], o, 64);
+#if defined(DCS_SLP_EXP) && DCS_SLP_EXP == 3
+          asm volatile("" : "+v"(vals[e]));
+#endif
+        }
       if (lane < EPV) {
         const int cl = wn * EPC + lane * 4;
 #pragma unroll

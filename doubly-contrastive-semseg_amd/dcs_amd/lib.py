@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdcs_hip.so")
+# DCS_LIB: another build of the same library (compiler experiments, tools/slp_repro.sh); read once, at import
+LIB_PATH = os.environ.get("DCS_LIB") or os.path.join(_HERE, "libdcs_hip.so")
 MAX_TAPS = 49
 
 
