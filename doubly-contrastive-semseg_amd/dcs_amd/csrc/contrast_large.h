@@ -307,26 +307,31 @@ __device__ __forceinline__ float count_valid_rows(const float* __restrict__ y, c
 // ------------------------------------------------------------------------------------------------------------------
 // dX_I += Gsym(I, J) X_J for a 128-row strip I and a chunk of 64-column tiles J; C <= 128.  512 threads: wave w owns the
 // strip rows 32 (w >> 1) .. +31 and the channels 64 (w & 1) .. +63 of the product.
-// Staging thread t owns rows (t >> 4) + 32 q (q = 0..3) and the four columns 4 (t & 15) .. +3 of every S tile: the fast
-// records of its 4 strip rows and 4 columns come from LDS per tile (<= 128 registers: two blocks per CU, so one block's
-// Gsym arithmetic overlaps the other's matrix-core phase).
+//
+// Two phases of work per tile -- forming Gsym(I,J) = G_ij + G_ji from the S tile and the two rows' records (~40 VALU
+// instructions per element, two exponentials) and the matrix-core product -- cost about the same, and a block's waves run
+// them in lock step between barriers: measured one after the other they ADD (122 us at A = 4864: 46 us of it the Gsym
+// arithmetic, 45 us the MFMAs, timing experiments with either switched off).  So the kernel is software-pipelined: the
+// tile images are double-buffered in LDS and, inside the product loop of tile J, every wave forms ONE EIGHTH of the Gsym
+// tile of J + 1 between two groups of 8 MFMAs (the matrix pipe runs a 32x32x2 MFMA for 64 cycles; the VALU is free
+// meanwhile).  Staging thread t owns rows (t >> 4) + 32 q (q < 4) and the columns 4 (t & 15) .. +3 of every S tile; slice g
+// covers row q = g >> 1, column pair g & 1.  The S / X values of tile J + 2 are requested as soon as those of J + 1 have been
+// consumed; the records of every tile row of the chunk are put into LDS once, in the prologue.  One barrier per tile.
 constexpr int DXM = 128;               // strip rows per block
 constexpr int DXT = 512;               // threads per block
 constexpr int GLD = TB + 4;            // LDS row stride of the Gsym tile [128][64]
-#ifndef DCS_DX_WPE
-#define DCS_DX_WPE 4                   // waves per SIMD the register budget allows: 4 = two 8-wave blocks per CU
-#endif
+constexpr int DX_CHMAX = 8;            // tiles per chunk (their row records stay in LDS)
 template <int MODE>
-__global__ __launch_bounds__(DXT, DCS_DX_WPE)
+__global__ __launch_bounds__(DXT, 2)
 void contrast_dx_kernel(const float* __restrict__ X, const int ldx, const float* __restrict__ y, const int ldy,
                         const float* __restrict__ mask, const int mb, const int A, const int C, const float it,
                         const float* __restrict__ S, const int lds, const float* __restrict__ rec, float* __restrict__ slab,
                         const int ntile, const int CH) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  float* Gs = reinterpret_cast<float*>(smem_raw);                 // [128][GLD]
-  float* XJ = Gs + DXM * GLD;                                     // [64][XLDL]
-  float* frJ = XJ + TB * XLDL;                                    // [64][8]
-  float* frI = frJ + TB * 8;                                      // [128][8] fast records of the strip rows
+  float* GsB = reinterpret_cast<float*>(smem_raw);                // [2][128][GLD]
+  float* XJB = GsB + 2 * DXM * GLD;                               // [2][64][XLDL]
+  float* frJB = XJB + 2 * TB * XLDL;                              // [CH <= 8][64][8] fast records of every tile row of the chunk
+  float* frI = frJB + DX_CHMAX * TB * 8;                          // [128][8] fast records of the strip rows
   float* red = frI + DXM * 8;                                     // [8]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, l31 = lane & 31, h = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
@@ -336,100 +341,131 @@ void contrast_dx_kernel(const float* __restrict__ X, const int ldx, const float*
   const int i0 = I2 * DXM;
   const float inv_av = 1.f / count_valid_rows(y, ldy, A, red);
   const int sr = tid >> 4, sc4 = (tid & 15) * 4;
-  if (tid < DXM) {
-    const int r = i0 + tid;
-    const bool in = r < A;
-    const float yv = in ? y[(long long)r * ldy] : -1.f;
+  auto put_record = [&](float* dst, const int row, const bool valid) {    // fast record of one row -> LDS
+    const bool in = valid && row < A;
+    const float yv = in ? y[(long long)row * ldy] : -1.f;
     float R[8];
-    make_fast<MODE>(R, rec + (long long)(in ? r : 0) * REC, yv, it, inv_av, in && yv >= 0.f);
-    *reinterpret_cast<float4*>(frI + tid * 8) = make_float4(R[0], R[1], R[2], R[3]);
-    *reinterpret_cast<float4*>(frI + tid * 8 + 4) = make_float4(R[4], R[5], R[6], R[7]);
-  }
-  float4 sv[4];                                                   // the next S tile (raw), 4 rows x 4 columns per thread
-  float4 xv[4];                                                   // the next X_J tile
-  float rj[8];                                                    // threads 0..63: the fast record of one row of the next tile
+    make_fast<MODE>(R, rec + (long long)(in ? row : 0) * REC, yv, it, inv_av, in && yv >= 0.f);
+    *reinterpret_cast<float4*>(dst) = make_float4(R[0], R[1], R[2], R[3]);
+    *reinterpret_cast<float4*>(dst + 4) = make_float4(R[4], R[5], R[6], R[7]);
+  };
+  if (tid < DXM) put_record(frI + tid * 8, i0 + tid, true);
+  for (int e = tid; e < (jend - jbeg) * TB; e += DXT) put_record(frJB + e * 8, jbeg * TB + e, true);
+  float4 sv[4];                                                   // S values (raw) of the tile being staged: 4 rows x 4 columns
+  float4 xv[4];                                                   // its X_J rows
   // S is [AP][AP] and AP is a multiple of 64, but a strip of 128 rows may reach past AP: clamp the row (its record is padding)
   long long soff[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) { const int r = i0 + sr + 32 * q; soff[q] = (long long)(r < lds ? r : lds - 1) * lds + sc4; }
-  auto load_tile = [&](int J, bool valid) {
+  auto load_s = [&](const int q, const int J) {
+    sv[q] = J < jend ? ldg4(S + soff[q] + J * TB) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto load_x = [&](const int q, const int J) {
+    const int e = tid + DXT * q, r = e >> 5, k = (e & 31) * 4;
+    const int row = J * TB + r;
+    xv[q] = (J < jend && row < A && k < C) ? ldg4(X + (long long)row * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store_x = [&](const int q, float* XJ) {
+    const int e = tid + DXT * q, r = e >> 5, k4 = (e & 31) * 4;
+    *reinterpret_cast<float4*>(&XJ[r * XLDL + k4]) = xv[q];
+  };
+  // the records the staging needs live in REGISTERS while it runs between the MFMAs (an LDS read there would put a
+  // s_waitcnt into the MFMA stream): the thread's 4 strip rows for the whole block, its 4 columns per tile
+  float Ri[4][8], Rc[4][8];
+  auto load_rc = [&](const float* frJ) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) sv[q] = valid ? ldg4(S + soff[q] + J * TB) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + DXT * q, r = e >> 5, k = (e & 31) * 4;
-      const int row = J * TB + r;
-      xv[q] = (valid && row < A && k < C) ? ldg4(X + (long long)row * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int c = 0; c < 4; ++c) {
+      const float4 a = *reinterpret_cast<const float4*>(frJ + (sc4 + c) * 8), b = *reinterpret_cast<const float4*>(frJ + (sc4 + c) * 8 + 4);
+      Rc[c][0] = a.x; Rc[c][1] = a.y; Rc[c][2] = a.z; Rc[c][3] = a.w; Rc[c][4] = b.x; Rc[c][5] = b.y; Rc[c][6] = b.z; Rc[c][7] = b.w;
     }
-    if (tid < TB) {
-      const int r = J * TB + tid;
-      const bool in = valid && r < A;
-      const float yv = in ? y[(long long)r * ldy] : -1.f;
-      make_fast<MODE>(rj, rec + (long long)(in ? r : 0) * REC, yv, it, inv_av, in && yv >= 0.f);
-    }
+  };
+  // one eighth of the Gsym tile of tile J: row q = g >> 1, columns sc4 + 2 (g & 1) + {0, 1}
+  auto stage_slice = [&](const int g, const int J, float* Gs) {
+    const int q = g >> 1, c0 = 2 * (g & 1);
+    const int ig = i0 + sr + 32 * q, jg = J * TB + sc4 + c0;
+    const float o0 = gsym_entry<MODE>(comp(sv[q], c0), Ri[q], Rc[c0], ig, jg, mask, mb);
+    const float o1 = gsym_entry<MODE>(comp(sv[q], c0 + 1), Ri[q], Rc[c0 + 1], ig, jg + 1, mask, mb);
+    *reinterpret_cast<float2*>(&Gs[(sr + 32 * q) * GLD + sc4 + c0]) = make_float2(o0, o1);
   };
   f32x16 acc[2];
 #pragma unroll
   for (int b = 0; b < 2; ++b)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[b][r] = 0.f;
-  load_tile(jbeg, true);
+  // prologue: tile jbeg is staged on its own, then the S / X values of jbeg + 1 are requested
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { load_s(q, jbeg); load_x(q, jbeg); }
+  __syncthreads();                                                 // the records are in LDS
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const float* rr = frI + (sr + 32 * q) * 8;
+    const float4 a = *reinterpret_cast<const float4*>(rr), b = *reinterpret_cast<const float4*>(rr + 4);
+    Ri[q][0] = a.x; Ri[q][1] = a.y; Ri[q][2] = a.z; Ri[q][3] = a.w; Ri[q][4] = b.x; Ri[q][5] = b.y; Ri[q][6] = b.z; Ri[q][7] = b.w;
+  }
+  load_rc(frJB);
+#pragma unroll
+  for (int g = 0; g < 8; ++g) stage_slice(g, jbeg, GsB);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { store_x(q, XJB); load_s(q, jbeg + 1); load_x(q, jbeg + 1); }
+  __syncthreads();
   for (int J = jbeg; J < jend; ++J) {
-    __syncthreads();                                               // readers of the previous tile images are done
-    if (tid < TB) {
-      *reinterpret_cast<float4*>(frJ + tid * 8) = make_float4(rj[0], rj[1], rj[2], rj[3]);
-      *reinterpret_cast<float4*>(frJ + tid * 8 + 4) = make_float4(rj[4], rj[5], rj[6], rj[7]);
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + DXT * q, r = e >> 5, k4 = (e & 31) * 4;
-      *reinterpret_cast<float4*>(&XJ[r * XLDL + k4]) = xv[q];
-    }
-    __syncthreads();
-    // Gsym tile: this thread's 4 columns' records, then 4 rows x 4 columns
-    float Rc[4][8];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const float4 a = *reinterpret_cast<const float4*>(frJ + (sc4 + c) * 8), b = *reinterpret_cast<const float4*>(frJ + (sc4 + c) * 8 + 4);
-      Rc[c][0] = a.x; Rc[c][1] = a.y; Rc[c][2] = a.z; Rc[c][3] = a.w; Rc[c][4] = b.x; Rc[c][5] = b.y; Rc[c][6] = b.z; Rc[c][7] = b.w;
-    }
-    const int jg0 = J * TB + sc4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int ig = i0 + sr + 32 * q;
-      const float4 ra = *reinterpret_cast<const float4*>(frI + (sr + 32 * q) * 8), rb = *reinterpret_cast<const float4*>(frI + (sr + 32 * q) * 8 + 4);
-      const float Rq[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
-      float4 gq;
-#if defined(DCS_DX_EXP) && DCS_DX_EXP == 1                          /* timing experiment: no Gsym arithmetic */
-      gq = make_float4(sv[q].x * Rq[0] + Rc[0][0], sv[q].y * Rq[0] + Rc[1][0], sv[q].z * Rq[0] + Rc[2][0], sv[q].w * Rq[0] + Rc[3][0]);
-      (void)ig; (void)jg0;
-#else
-      gq.x = gsym_entry<MODE>(sv[q].x, Rq, Rc[0], ig, jg0, mask, mb);
-      gq.y = gsym_entry<MODE>(sv[q].y, Rq, Rc[1], ig, jg0 + 1, mask, mb);
-      gq.z = gsym_entry<MODE>(sv[q].z, Rq, Rc[2], ig, jg0 + 2, mask, mb);
-      gq.w = gsym_entry<MODE>(sv[q].w, Rq, Rc[3], ig, jg0 + 3, mask, mb);
-#endif
-      *reinterpret_cast<float4*>(&Gs[(sr + 32 * q) * GLD + sc4]) = gq;
-    }
-    __builtin_amdgcn_sched_barrier(0);                             // the Gsym arithmetic first: its registers die here
-    load_tile(J + 1, J + 1 < jend);                                // prefetch behind the product
-    __syncthreads();
+    const int b = (J - jbeg) & 1;
+    const float* Gs = GsB + b * (DXM * GLD);
+    const float* XJ = XJB + b * (TB * XLDL);
+    float* GsN = GsB + (b ^ 1) * (DXM * GLD);
+    float* XJN = XJB + (b ^ 1) * (TB * XLDL);
+    const bool more = J + 1 < jend;                                // block-uniform
     // dX[i = 32 wm + ..][c = 64 wn + 32 b + ..] += sum_k Gsym[i][k] X_J[k][c]
     // A fragment: lane (i = l31, k = 8 g + 4 h + e); B fragment: lane (c = l31, k = 8 g + 4 h + e)
-#if defined(DCS_DX_EXP) && DCS_DX_EXP == 2                          /* timing experiment: one eighth of the matrix-core work */
-    for (int g = 0; g < 1; ++g) {
-#else
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-#endif
-      const float4 af = *reinterpret_cast<const float4*>(&Gs[(32 * wm + l31) * GLD + 8 * g + 4 * h]);
+    // operands of one group of 8 MFMAs (k = 8 g .. 8 g + 7): read one group AHEAD of their use, so that no MFMA waits for LDS
+    float4 af[2];
+    float xb[2][8];
+    auto load_ops = [&](const int g, const int slot) {
+      af[slot] = *reinterpret_cast<const float4*>(&Gs[(32 * wm + l31) * GLD + 8 * g + 4 * h]);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const float* xb = &XJ[(8 * g + 4 * h + e) * XLDL + 64 * wn + l31];
-#pragma unroll
-        for (int b = 0; b < 2; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(af, e), xb[32 * b], acc[b], 0, 0, 0);
+        const float* p = &XJ[(8 * g + 4 * h + e) * XLDL + 64 * wn + l31];
+        xb[slot][2 * e] = p[0]; xb[slot][2 * e + 1] = p[32];
       }
+    };
+    auto mfma_group = [&](const int g) {
+      const int slot = g & 1;
+      if (g + 1 < 8) load_ops(g + 1, slot ^ 1);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb)
+          acc[bb] = __builtin_amdgcn_mfma_f32_32x32x2f32(comp(af[slot], e), xb[slot][2 * e + bb], acc[bb], 0, 0, 0);
+    };
+    load_ops(0, 0);
+    if (more) {
+      // groups 0..3: matrix cores only (the S / X values of tile J + 1 were requested at the end of the last step: they
+      // are ~4 MFMA groups old when the staging first touches them, so its s_waitcnt finds them delivered)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) mfma_group(g);
+      load_rc(frJB + (J + 1 - jbeg) * (TB * 8));
+#pragma unroll
+      for (int g = 4; g < 8; ++g) {
+        mfma_group(g);
+        // behind those 8 MFMAs: one quarter of the next tile's Gsym and of its X rows
+        stage_slice(2 * (g - 4), J + 1, GsN);
+        stage_slice(2 * (g - 4) + 1, J + 1, GsN);
+        store_x(g - 4, XJN);
+        // issue order: one MFMA (64 cycles of the matrix pipe), then the independent VALU instructions
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 20, 0);
+        }
+      }
+      // everything staged: request the values of tile J + 2 (no load is in flight while older values are being read)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { load_s(q, J + 2); load_x(q, J + 2); }
+    } else {
+#pragma unroll
+      for (int g = 0; g < 8; ++g) mfma_group(g);
     }
+    __syncthreads();
   }
   // every wave owns a disjoint 32 x 64 block of the strip's partial dX: straight into this chunk's slab
   float* o = slab + (long long)chunk * A * C;
@@ -559,11 +595,12 @@ inline int launch_large(const float* X, int ldx, const float* y, int ldy, const 
   }
   // dX: 128-row strips x chunks of tiles, <= 16 chunks (slabs), ~2 blocks of 8 waves per CU
   const int nstrip = (A + DXM - 1) / DXM;
-  int CH4 = (ntile * nstrip + (DCS_DX_WPE >= 4 ? 511 : 639)) / (DCS_DX_WPE >= 4 ? 512 : 640);
-  if (CH4 < (ntile + 15) / 16) CH4 = (ntile + 15) / 16;
+  int CH4 = (ntile * nstrip + 511) / 512;                          // one 8-wave block per CU: two rounds of blocks
+  if (CH4 < (ntile + 15) / 16) CH4 = (ntile + 15) / 16;           // <= 16 slabs
   if (CH4 < 1) CH4 = 1;
+  if (CH4 > DX_CHMAX) return DCS_E_UNSUPPORTED;                    // cannot happen for A <= LARGE_MAX (128 tiles / 16)
   const int nchunk = (ntile + CH4 - 1) / CH4;
-  const size_t sh_d = (size_t)(DXM * GLD + TB * XLDL + TB * 8 + DXM * 8 + 8) * sizeof(float);
+  const size_t sh_d = (size_t)(2 * DXM * GLD + 2 * TB * XLDL + DX_CHMAX * TB * 8 + DXM * 8 + 8) * sizeof(float);
   auto kd0 = contrast_dx_kernel<0>;
   auto kd1 = contrast_dx_kernel<1>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(mode == 0 ? kd0 : kd1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh_d) != hipSuccess)
