@@ -251,10 +251,11 @@ def hbm_family_pass(ops, one_step, steps=2):
 def similarity_bench(ops, dev, ts, reps=20):
     """BASELINE.json's second metric: TFLOP/s of the pixel-contrastive similarity / InfoNCE loss, forward AND backward
     (utils/loss.py:339-389), outside the timed region, HIP events.  Algorithmic FLOPs = 2 A^2 d (S = X X^T) +
-    4 A^2 d (dX = (G + G^T) X) = 6 A^2 d; the fused kernels execute more than that (S tiles are
-    recomputed instead of stored: contrast_fused.hip).  A = anchors this rank sampled in the last step (<= 608 rows of
-    128: two launches) and A_global = the 8-rank gathered set of C4 (4864 rows: symmetric tile sweeps).
-    `unfused_*` = the round-1 chain (GEMM writes S, row kernel, symmetrize, transpose, GEMM) on the same data."""
+    4 A^2 d (dX = (G + G^T) X) = 6 A^2 d.  A = anchors this rank sampled in the last step (<= 608 rows of
+    128: one launch, the S strips never leave LDS) and A_global = the 8-rank gathered set of C4 (4864 rows: S computed once
+    on the matrix cores -- upper-triangular tiles only, i.e. HALF of the 2 A^2 d similarity FLOPs are executed -- kept in
+    the workspace, one block per row for the statistics, G + G^T formed on the fly in the gradient product:
+    csrc/contrast_large.h).  `unfused_*` = the round-1 chain (GEMM writes S, row kernel, symmetrize, transpose, GEMM)."""
     la = ts.pixelcontrast_criterion.last_anchors
     a_rank = int(la[2].numel()) if la is not None else 608
     out = {"unit": "TFLOP/s", "peak": PEAK_FP32_MFMA_TFLOPS, "dim": 128,
@@ -279,7 +280,9 @@ def similarity_bench(ops, dev, ts, reps=20):
         out[tag] = res
     gl = out["global"]
     out["similarity_kernel_frac_global"] = gl["loss_tflops"] / PEAK_FP32_MFMA_TFLOPS     # whole fused loss at the C4 size
-    out["note"] = "rank size (A <= 608): 95 MFLOP = 0.6 us at peak, i.e. launch-latency bound: two launches"
+    out["executed_flops_note"] = ("fp32 MFMA (v_mfma_f32_32x32x2_f32) throughout; executed matrix-core FLOPs at A_global = "
+                                  "A^2 d (S, upper triangle) + 2 A^2 d (dX) = 3 A^2 d = half of the algorithmic 6 A^2 d")
+    out["note"] = "rank size (A <= 608): 95 MFLOP = 0.6 us at peak, i.e. latency bound: one launch (grid barrier between the phases)"
     return out
 
 

@@ -134,11 +134,11 @@ __device__ __forceinline__ float pos_weight(const float* __restrict__ mask, cons
 // ------------------------------------------------------------------------------------------------------------------
 // small-A statistics: block = one 16-row strip, S strip resident in LDS.
 template <typename ACC, int NW>
-__global__ __launch_bounds__(NW * 64)
-void contrast_small_stats_kernel(const float* __restrict__ X, const int ldx, const float* __restrict__ y, const int ldy,
-                                 const float* __restrict__ mask, const int mb, const int A, const int C, const int mode,
-                                 const float it, float* __restrict__ rec, float* __restrict__ loss_row, const int AP) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+__device__ __forceinline__
+void contrast_small_stats_body(unsigned char* smem_raw, const float* __restrict__ X, const int ldx, const float* __restrict__ y,
+                               const int ldy, const float* __restrict__ mask, const int mb, const int A, const int C,
+                               const int mode, const float it, float* __restrict__ rec, float* __restrict__ loss_row,
+                               const int AP) {
   ACC* Ss = reinterpret_cast<ACC*>(smem_raw);                       // [16][AP]
   float* ys = reinterpret_cast<float*>(Ss + 16 * AP);               // [AP]
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, li = lane & 15, q = lane >> 4;
@@ -263,16 +263,17 @@ __device__ __forceinline__ float g_entry(const ACC s, const float* __restrict__ 
 // small-A final sweep: dX_I = sum_J (G + G^T)(I,J) X_J, one block per 16-row strip, waves split the column tiles.
 // gsym_out != null (C > 128: the feature width of DeepLab's pixel contrast): G + G^T is written out [A][ldg] instead
 // and the caller finishes dX with one GEMM.
-template <typename ACC, int NW>
-__global__ __launch_bounds__(NW * 64)
-void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, const float* __restrict__ y, const int ldy,
-                                 const float* __restrict__ mask, const int mb, const int A, const int C, const int mode,
-                                 const float it, const float* __restrict__ rec, const float* __restrict__ loss_row,
-                                 float* __restrict__ loss, float* __restrict__ dX, const int lddx,
-                                 float* __restrict__ gsym_out, const int ldg) {
+// FUSED (one cooperative launch, see contrast_small_fused_kernel): the S strip of the statistics phase is still in LDS
+// (Sstrip [16][AP]), so the tiles are read back instead of being recomputed.
+template <typename ACC, int NW, bool FUSED>
+__device__ __forceinline__
+void contrast_small_final_body(unsigned char* smem_raw, const ACC* Sstrip, const int AP, const float* __restrict__ X, const int ldx,
+                               const float* __restrict__ y, const int ldy, const float* __restrict__ mask, const int mb,
+                               const int A, const int C, const int mode, const float it, const float* __restrict__ rec,
+                               const float* __restrict__ loss_row, float* __restrict__ loss, float* __restrict__ dX,
+                               const int lddx, float* __restrict__ gsym_out, const int ldg) {
   constexpr int XLD = 144;                       // 128 + 16: rows 16 banks apart -> conflict-free k-strided B reads
   constexpr int GLD = 17;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   float* sm = reinterpret_cast<float*>(smem_raw);
   float* recI = sm;                              // [16][REC]
   float* yI = recI + 16 * REC;                   // [16]
@@ -329,7 +330,13 @@ void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, con
     const float rj[REC] = {rna.x, rna.y, rna.z, rna.w, rnb.x, rnb.y, rnb.z, rnb.w};
     const float yj = yn;
     prefetch(jt + NW);
-    const typename Mfma16<ACC>::acc_t acc = regs ? s_tile_regs<ACC>(xa, xb) : s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
+    typename Mfma16<ACC>::acc_t acc;
+    if constexpr (FUSED) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = Sstrip[Mfma16<ACC>::row(lane, r) * AP + 16 * jt + li];
+    } else {
+      acc = regs ? s_tile_regs<ACC>(xa, xb) : s_tile<ACC, 8>(xa, X, ldx, C, rowI, rowJ, q);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int il = Mfma16<ACC>::row(lane, r);
@@ -404,14 +411,72 @@ void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, con
   }
 }
 
+template <typename ACC, int NW>
+__global__ __launch_bounds__(NW * 64)
+void contrast_small_stats_kernel(const float* __restrict__ X, const int ldx, const float* __restrict__ y, const int ldy,
+                                 const float* __restrict__ mask, const int mb, const int A, const int C, const int mode,
+                                 const float it, float* __restrict__ rec, float* __restrict__ loss_row, const int AP) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  contrast_small_stats_body<ACC, NW>(smem_raw, X, ldx, y, ldy, mask, mb, A, C, mode, it, rec, loss_row, AP);
+}
+
+template <typename ACC, int NW>
+__global__ __launch_bounds__(NW * 64)
+void contrast_small_final_kernel(const float* __restrict__ X, const int ldx, const float* __restrict__ y, const int ldy,
+                                 const float* __restrict__ mask, const int mb, const int A, const int C, const int mode,
+                                 const float it, const float* __restrict__ rec, const float* __restrict__ loss_row,
+                                 float* __restrict__ loss, float* __restrict__ dX, const int lddx,
+                                 float* __restrict__ gsym_out, const int ldg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  contrast_small_final_body<ACC, NW, false>(smem_raw, nullptr, 0, X, ldx, y, ldy, mask, mb, A, C, mode, it, rec, loss_row, loss, dX,
+                                            lddx, gsym_out, ldg);
+}
+
+// Both phases in ONE cooperative launch (A <= 1024: <= 64 blocks, all resident): statistics with the S strip in LDS, a
+// grid-wide barrier (every block needs the records of ALL rows for G_ji), then the gradient sweep that reads the strip
+// back from LDS instead of recomputing S.  One launch latency instead of two dependent ones, half the similarity FLOPs.
+struct SmallFusedArgs {
+  const float* X; int ldx; const float* y; int ldy; const float* mask; int mb, A, C, mode; float it;
+  float* rec; float* loss_row; float* loss; float* dX; int lddx; float* gsym; int ldg, AP, final_off;
+  unsigned* sync;                      // [2] in the workspace: arrivals at the barrier, departures (the last one re-zeroes both)
+};
+template <typename ACC, int NW>
+__global__ __launch_bounds__(NW * 64)
+void contrast_small_fused_kernel(const SmallFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  contrast_small_stats_body<ACC, NW>(smem_raw, a.X, a.ldx, a.y, a.ldy, a.mask, a.mb, a.A, a.C, a.mode, a.it, a.rec, a.loss_row, a.AP);
+  // grid-wide barrier on a counter in the workspace (zero on entry: dcs_contrast_fused's contract; <= 64 blocks of one per
+  // CU are all resident).  Release: the records / loss rows of this strip; acquire: those of every other strip.  The wait
+  // is bounded (a hung peer must not hang the device): ~1 s of polling, then the block goes on.
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    atomicAdd(a.sync, 1u);
+    const unsigned target = gridDim.x;
+    for (unsigned spin = 0; spin < (1u << 22); ++spin) {
+      if (__hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+      __builtin_amdgcn_s_sleep(2);
+    }
+    __threadfence();
+  }
+  __syncthreads();
+  contrast_small_final_body<ACC, NW, true>(smem_raw + a.final_off, reinterpret_cast<const ACC*>(smem_raw), a.AP, a.X, a.ldx, a.y,
+                                           a.ldy, a.mask, a.mb, a.A, a.C, a.mode, a.it, a.rec, a.loss_row, a.loss, a.dX, a.lddx,
+                                           a.gsym, a.ldg);
+  // the last block to leave hands the counters back as zeros (the next call's contract)
+  __syncthreads();
+  if (threadIdx.x == 0 && atomicAdd(a.sync + 1, 1u) == gridDim.x - 1) { a.sync[0] = 0u; a.sync[1] = 0u; __threadfence(); }
+}
+
 #include "contrast_large.h"
 
 constexpr int SMALL_MAX = 1024;
 constexpr int NW_S = 8;
+#define g_small_fused (dcs_config().contrast_fused != 0)
 
 template <typename ACC>
 int launch_small(const float* X, int ldx, const float* y, int ldy, const float* mask, int mb, int A, int C, int mode,
-                 float it, float* loss, float* dX, int lddx, float* gsym, int ldg, float* ws, hipStream_t s) {
+                 float it, float* loss, float* dX, int lddx, float* gsym, int ldg, float* ws, float* sync, hipStream_t s) {
   float* rec = ws;
   float* loss_row = ws + (size_t)A * REC;
   int AP = (A + 15) / 16 * 16;
@@ -420,10 +485,21 @@ int launch_small(const float* X, int ldx, const float* y, int ldy, const float* 
   const int nb = (A + 15) / 16;
   auto k1 = contrast_small_stats_kernel<ACC, NW_S>;
   auto k2 = contrast_small_final_kernel<ACC, NW_S>;
+  const size_t sh2 = (size_t)(16 * REC + 16 + NW_S + 4 + NW_S * 16 * 17 + 4 + NW_S * 16 * 144) * 4;
+  // one cooperative launch when both phases' LDS fits next to each other (always for the pixel contrast, A <= 1024)
+  const size_t off = (sh1 + 15) & ~(size_t)15;
+  if (off + sh2 <= 160 * 1024 && sync != nullptr && g_small_fused) {
+    auto kf = contrast_small_fused_kernel<ACC, NW_S>;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(off + sh2)) != hipSuccess)
+      return DCS_E_LAUNCH;
+    SmallFusedArgs a{X, ldx, y, ldy, mask, mb, A, C, mode, it, rec, loss_row, loss, dX, lddx, gsym, ldg, AP, (int)off,
+                     reinterpret_cast<unsigned*>(sync)};
+    hipLaunchKernelGGL(kf, dim3(nb), dim3(NW_S * 64), off + sh2, s, a);
+    DCS_LAUNCH_RET();
+  }
   if (sh1 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh1) != hipSuccess)
     return DCS_E_LAUNCH;
   hipLaunchKernelGGL(k1, dim3(nb), dim3(NW_S * 64), sh1, s, X, ldx, y, ldy, mask, mb, A, C, mode, it, rec, loss_row, AP);
-  const size_t sh2 = (size_t)(16 * REC + 16 + NW_S + 4 + NW_S * 16 * 17 + 4 + NW_S * 16 * 144) * 4;
   if (sh2 > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(k2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh2) != hipSuccess)
     return DCS_E_LAUNCH;
   hipLaunchKernelGGL(k2, dim3(nb), dim3(NW_S * 64), sh2, s, X, ldx, y, ldy, mask, mb, A, C, mode, it, rec, loss_row, loss, dX,
@@ -442,7 +518,7 @@ extern "C" int dcs_contrast_fused_ws(int A, int C, int64_t* floats) {
 
 extern "C" int dcs_contrast_fused(const float* X, int ldx, const float* y, int ldy, const float* mask, int mask_b, int A,
                                   int C, int mode, float inv_temp, float* loss, float* dX, int lddx, float* gsym, int ldg,
-                                  float* ws, int64_t ws_floats, void* stream) {
+                                  float* ws, int64_t ws_floats, uint32_t* sync, void* stream) {
   DCS_CHECK_ARG(X && y && loss && ws && A > 0 && C > 0 && (C & 3) == 0 && (ldx & 3) == 0 && ldx >= C && ldy >= 1);
   DCS_CHECK_ARG(mode == 0 || mode == 1);
   DCS_CHECK_ARG(dcs_aligned16(X) && dcs_aligned16(ws) && (!mask || (mode == 1 && mask_b > 0 && A % mask_b == 0)));
@@ -457,6 +533,7 @@ extern "C" int dcs_contrast_fused(const float* X, int ldx, const float* y, int l
     if (A > LARGE_MAX) return DCS_E_UNSUPPORTED;                   // the row kernel keeps a row in <= 128 registers per lane
     return launch_large(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, s);
   }
-  if (mode == 1) return launch_small<double>(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, s);
-  return launch_small<float>(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, s);
+  float* sy = reinterpret_cast<float*>(sync);
+  if (mode == 1) return launch_small<double>(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, sy, s);
+  return launch_small<float>(X, ldx, y, ldy, mask, mask_b, A, C, mode, inv_temp, loss, dX, lddx, gsym, ldg, ws, sy, s);
 }

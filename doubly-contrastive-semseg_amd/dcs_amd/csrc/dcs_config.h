@@ -10,6 +10,7 @@ struct DcsConfig {
   int wgrad_roll;     // DCS_WGRAD_ROLL  (1)   0 = nine-tap weight gradient instead of the rolling-window kernel
   int conv_bk16;      // DCS_CONV_BK16   (0)   1 = 16-channel chunks everywhere in the fp32 gather
   int wgrad_ch32;     // DCS_WGRAD_CH32  (0)   1 = 32-pixel chunks in the generic fp32 weight gradient
+  int contrast_fused; // DCS_CONTRAST_FUSED (1) 0 = two launches for the small similarity family (A/B, tests)
 };
 extern DcsConfig g_dcs_config;
 static inline const DcsConfig& dcs_config() { return g_dcs_config; }

@@ -99,7 +99,7 @@ SIGNATURES = {
     "dcs_label_boundary_weights": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _P],
     "dcs_confusion": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_contrast_fused_ws": [_I, _I, C.POINTER(C.c_int64)],
-    "dcs_contrast_fused": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _I, _P, _L, _P],
+    "dcs_contrast_fused": [_P, _I, _P, _I, _P, _I, _I, _I, _I, _F, _P, _P, _I, _P, _I, _P, _L, _P, _P],
     "dcs_contrast_rows": [_P, _P, _P, _P, _I, _I, _I, _F, _P],
     "dcs_symmetrize": [_P, _P, _I, _I, _P],
     "dcs_sum_scalar": [_P, _P, _I, _F, _P],

@@ -1010,9 +1010,12 @@ def scatter_rows_bilinear(gX, rowidx, gfeat, OH, OW):
           _stream())
 
 
+_contrast_sync = {}          # device index -> two zeroed uint32 (the grid barrier of the one-launch small family)
+
+
 def contrast_fwd_bwd(X, labels, mode, temperature=0.07, mask=None):
-    """Contrastive loss on anchors X [A,C] (view-major) with float labels [A]; forward and backward fused, the
-    similarity matrix is never written (dcs_contrast_fused).
+    """Contrastive loss on anchors X [A,C] (view-major) with float labels [A]; forward and backward in one library call
+    (dcs_contrast_fused: one launch for A <= 1024).
 
     mode 0: pixel contrast (utils/loss.py:339-389); 1: SupCon/SimCLR (:175-204).  X may be a row-strided view
     (X.stride(1) == 1, X.stride(0) % 4 == 0) and labels a strided 1-D view -- e.g. columns of the packed all-gather
@@ -1034,17 +1037,20 @@ def contrast_fwd_bwd(X, labels, mode, temperature=0.07, mask=None):
     ws = torch.empty((need.value,), device=X.device, dtype=_F32)
     loss = torch.empty((1,), device=X.device, dtype=_F32)
     it = 1.0 / temperature
+    sync = _contrast_sync.get(X.device.index)
+    if sync is None:
+        sync = _contrast_sync[X.device.index] = torch.zeros((2,), device=X.device, dtype=torch.int32)
     if Cc <= 128:
         dX = torch.empty((A, Cc), device=X.device, dtype=_F32)
         _call("dcs_contrast_fused", _p(X), ldx, _p(labels), ldy, _p(mask), mb, A, Cc, mode, it, _p(loss), _p(dX), Cc, None, 0,
-              _p(ws), need.value, _stream())
+              _p(ws), need.value, _p(sync), _stream())
         return loss, dX
     # wide features (DeepLab's 2048-channel pixel contrast): the kernel hands back Gs = G + G^T [A, ld] and dX = Gs X is
     # one GEMM with K = ld (zero padded), weights X^T
     ld = -(-A // 32) * 32
     Gs = torch.zeros((A, ld), device=X.device, dtype=_F32) if ld != A else torch.empty((A, ld), device=X.device, dtype=_F32)
     _call("dcs_contrast_fused", _p(X), ldx, _p(labels), ldy, _p(mask), mb, A, Cc, mode, it, _p(loss), None, 0, _p(Gs), ld,
-          _p(ws), need.value, _stream())
+          _p(ws), need.value, _p(sync), _stream())
     Xp = torch.zeros((ld, Cc), device=X.device, dtype=_F32)
     Xp[:A].copy_(X)
     Xt = transpose(Xp)                                   # [C, ld]

@@ -32,8 +32,8 @@ extern "C" {
 /* ---- library switches -------------------------------------------------------------------------
  * A/B and test switches of the kernels (no reference counterpart).  Their initial values are read from the environment
  * ONCE, when the library is loaded (DCS_BN_NT, DCS_NT_MIN_MB, DCS_X3_BM128, DCS_X3_HALO, DCS_WGRAD_ROLL, DCS_CONV_BK16,
- * DCS_WGRAD_CH32); no launcher reads the environment.  Names: "bn_nt", "nt_min_mb", "x3_bm128", "x3_halo", "wgrad_roll",
- * "conv_bk16", "wgrad_ch32" (csrc/dcs_config.h says what each one does).  Not thread-safe against concurrent launches. */
+ * DCS_WGRAD_CH32, DCS_CONTRAST_FUSED); no launcher reads the environment.  Names: "bn_nt", "nt_min_mb", "x3_bm128",
+ * "x3_halo", "wgrad_roll", "conv_bk16", "wgrad_ch32", "contrast_fused" (csrc/dcs_config.h says what each one does).  Not thread-safe against concurrent launches. */
 int dcs_set_option(const char* name, int value);
 int dcs_get_option(const char* name, int* value);
 
@@ -330,7 +330,7 @@ int dcs_gather_rows_bilinear(const float* feat, const int32_t* rowidx, float* X,
 int dcs_scatter_rows_bilinear(const float* gX, const int32_t* rowidx, float* gfeat, int A, int C, int N, int IH, int IW,
                               int OH, int OW, void* stream);
 /* ---- fused similarity / InfoNCE loss (utils/loss.py:339-389 PixelContrastLoss._contrastive = mode 0,
- *      utils/loss.py:175-204 SupConLoss = mode 1), forward AND backward, S = X X^T never written -----------------
+ *      utils/loss.py:175-204 SupConLoss = mode 1), forward AND backward in one call -------------------------------
  * X [A][ldx] anchors (C <= ldx channels used, ldx % 4 == 0), y[i*ldy] float labels; y < 0 marks a padding row (fixed-
  * shape all-gather of the data-parallel step): it contributes to no maximum, norm, denominator, loss or gradient.
  * mask (nullable, mode 1 only): explicit [mask_b][mask_b] positive weights tiled over the views like
@@ -338,13 +338,17 @@ int dcs_scatter_rows_bilinear(const float* gX, const int32_t* rowidx, float* gfe
  * loss[0] = mean over the valid rows.  Exactly one of:
  *   dX [A][lddx] = d loss / d X = (G + G^T) X            (C <= 128), or
  *   gsym [A][ldg] = G + G^T, G_ij = d loss / d S_ij      (any C; the caller finishes dX with one GEMM).
- * ws: scratch of dcs_contrast_fused_ws(A, C) floats.  A <= 1024: two launches (row statistics with the S strip resident in
- * LDS; final sweep recomputing S tiles on the matrix cores); larger A: symmetric tile sweeps (see contrast_fused.hip).
+ * ws: scratch of dcs_contrast_fused_ws(A, C) floats.  A <= 1024: the S strips stay in LDS (statistics, then the gradient
+ * sweep); larger A: S is computed once into ws (upper-triangular MFMA tiles), one block per row derives the row records,
+ * the gradient product forms G + G^T on the fly (csrc/contrast_large.h).
+ * sync (nullable): two uint32 in device memory that are ZERO on entry and are handed back as zeros.  With it the A <= 1024
+ * family runs as ONE launch (a grid-wide barrier on that counter between the two phases, <= 64 resident blocks; the gradient
+ * sweep then reads the S strip back from LDS); without it, as two launches.  One call at a time per sync word.
  * Rows without positives give NaN like the reference. */
 int dcs_contrast_fused_ws(int A, int C, int64_t* floats);
 int dcs_contrast_fused(const float* X, int ldx, const float* y, int ldy, const float* mask, int mask_b, int A, int C,
                        int mode, float inv_temp, float* loss, float* dX, int lddx, float* gsym, int ldg, float* ws,
-                       int64_t ws_floats, void* stream);
+                       int64_t ws_floats, uint32_t* sync, void* stream);
 
 /* ---- contrastive rows, unfused form (kept for A/B measurements in bench.py; not used by the product path) --------
  * S [A,ld] = C C^T (from dcs_conv_gather in 1x1 mode), scaled by inv_temp = 1/T on read.  For every row i < A:

@@ -399,6 +399,18 @@ def test_contrast_fwd_bwd(ops, A, mode):
     assert torch.equal(loss, loss2) and torch.equal(dX, dX2)
 
 
+@pytest.mark.parametrize("A,mode", [(76, 0), (608, 0), (1000, 0), (64, 1), (256, 1)])
+def test_contrast_small_family_one_launch_equals_two(ops, libopt, A, mode):
+    """A <= 1024: the cooperative single launch (statistics, grid barrier, gradient sweep reading the S strip back from
+    LDS) performs the arithmetic of the two-launch form (which recomputes the same S tiles): bitwise the same loss and dX."""
+    X, y = _contrast_case(A, mode)
+    libopt("contrast_fused", 1)
+    l1, d1 = ops.contrast_fwd_bwd(X.to(DEV), y.to(DEV), mode)
+    libopt("contrast_fused", 0)
+    l0, d0 = ops.contrast_fwd_bwd(X.to(DEV), y.to(DEV), mode)
+    assert torch.equal(l0, l1) and torch.equal(d0, d1)
+
+
 @pytest.mark.parametrize("A,cap,world,mode", [(37, 64, 2, 0), (300, 608, 2, 0), (10, 16, 4, 1), (500, 608, 4, 0)])
 def test_contrast_padded_strided_gather_buffer(ops, A, cap, world, mode):
     """The data-parallel layout: [world * cap] rows of 132 floats (128 channels, label, 3 pad), label -1 on the rows a
