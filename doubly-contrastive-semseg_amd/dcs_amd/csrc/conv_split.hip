@@ -43,6 +43,30 @@ __device__ __forceinline__ void split3_quad(const float4 v, uint2& p1, uint2& p2
   split3_pair(v.z, v.w, p1.y, p2.y, p3.y);
 }
 
+// ---- fp32 through TWO fp16 pieces (round 3; forward 3x3 convolutions, see conv3x3_x3w_body<.., NP = 2>) ----------------
+// x * 2^k = h1 + h2 + r with h1 = fp16(x 2^k), h2 = fp16(x 2^k - h1): two 11-bit significands, |r| <= 2^-24 |x 2^k| -- the
+// rounding of ONE fp32 -- as long as h2 stays normal (|x 2^k| >= 2^-2; below that its absolute error is 2^-25: negligible in
+// a sum with terms of order one) and nothing overflows (|x 2^k| < 65504).  A product needs h1 h1' + h1 h2' + h2 h1' (the
+// dropped h2 h2' is <= 2^-24 |x x'|): THREE v_mfma_f32_32x32x16_f16 where the bf16 split needs six -- fp16 buys its third of
+// the significand with the exponent range, which a power-of-two scale per operand (exact) gives back: activations are
+// scaled by 2^X2H_KX (|x| < 16384), weights by 2^X2H_KW (|w| < 64), the accumulator by 2^-(KX + KW).
+constexpr int X2H_KX = 2, X2H_KW = 10;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2h_pair(const float x0, const float x1, unsigned& q1, unsigned& q2) {
+  const f32x2 v = {x0, x1};
+  const f16x2 p1 = __builtin_convertvector(v, f16x2);                 // round to nearest even
+  const f32x2 f1 = __builtin_convertvector(p1, f32x2);
+  const f32x2 r1 = {x0 - f1.x, x1 - f1.y};                            // exact
+  const f16x2 p2 = __builtin_convertvector(r1, f16x2);
+  q1 = __builtin_bit_cast(unsigned, p1);
+  q2 = __builtin_bit_cast(unsigned, p2);
+}
+__device__ __forceinline__ void split2h_quad(const float4 v, const float sc, uint2& p1, uint2& p2) {
+  split2h_pair(v.x * sc, v.y * sc, p1.x, p2.x);
+  split2h_pair(v.z * sc, v.w * sc, p1.y, p2.y);
+}
+
 // w [rows][wstride] fp32 -> out [rows][wstride / 16][3][16] bf16 (the LDS row image of one 16-channel chunk)
 __global__ void split_weight_kernel(const float* __restrict__ w, uint2* __restrict__ out, const long long n4,
                                     const int wstride) {
@@ -1235,7 +1259,10 @@ void conv3x3_x3_kernel(const float* __restrict__ src, const unsigned char* __res
 // that one: rounding-bias cancellation as in conv3x3_x3_kernel, no XOR in the kernel).  A wave loads the fragments of
 // the NEXT tap while it multiplies the current one; the halo is the only LDS tenant, so barriers remain only around its
 // replacement every nine taps.
-template <int BN, int TH>
+// NP = 3: three bf16 pieces, six products (above).  NP = 2: two fp16 pieces, three products (split2h_quad; the weight
+// fragments come from dcs_split_weight_frag in its fp16 form): same structure, LDS row = [piece 1: 16 fp16][piece 2][16 B
+// pad] = 80 B (5 x 16 B: conflict-free b128 reads), results scaled back by 2^-(X2H_KX + X2H_KW) before the epilogue.
+template <int BN, int TH, int NP = 3>
 __device__ __forceinline__
 void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
                         float* __restrict__ dst, const DcsConvGeom& g, const int accumulate, const int ntiles,
@@ -1243,7 +1270,8 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
                         const unsigned neg_off, const BlkId bi) {
   constexpr int BM = 32 * TH, HWD = 34, HROWS = (TH + 2) * HWD;
   constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = 2, TN = BN / (WN * 32);
-  constexpr int A_BYTES = HROWS * X3_ROWB;
+  constexpr int ROWB = NP == 3 ? X3_ROWB : 80;
+  constexpr int A_BYTES = HROWS * ROWB;
   constexpr int EPI_FLOATS = 4 * 32 * (TN * 32 + 4) + WM * BN * 2;
   constexpr int SMEM_FLOATS = (A_BYTES / 4) > EPI_FLOATS ? (A_BYTES / 4) : EPI_FLOATS;
   constexpr int NH = (HROWS * 4 + 255) / 256;
@@ -1277,13 +1305,13 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
     rowoff[tid] = (((long long)n * g.DH + (y0 + ry)) * g.DW + (x0 + px)) * g.dst_cstride;
   }
   if (tid < 9) {
-    s_ho[tid] = (g.offy[tid] * HWD + g.offx[tid]) * X3_ROWB;
+    s_ho[tid] = (g.offy[tid] * HWD + g.offx[tid]) * ROWB;
     s_wc[tid] = g.wofs[tid] >> 4;                                 // first K chunk of the tap
   }
   const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
   const int wchunks = g.wstride >> 4;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n * img_elems, img_elems * 4);
-  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wfrag), 2ll * wchunks * J * 3 * 1024);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wfrag), 2ll * wchunks * J * NP * 1024);
 
   int h_off[NH];
   float lim[NH];
@@ -1317,15 +1345,22 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
       if (NH * 64 != HROWS && hrow >= HROWS) continue;
       float4 v = rh[j];
       if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[j]);
-      uint2 p1, p2, p3;
-      split3_quad(v, p1, p2, p3);
-      unsigned char* q = sm + hrow * X3_ROWB + lcol4 * 8;
-      *reinterpret_cast<uint2*>(q) = p1;
-      *reinterpret_cast<uint2*>(q + 32) = p2;
-      *reinterpret_cast<uint2*>(q + 64) = p3;
+      unsigned char* q = sm + hrow * ROWB + lcol4 * 8;
+      if constexpr (NP == 3) {
+        uint2 p1, p2, p3;
+        split3_quad(v, p1, p2, p3);
+        *reinterpret_cast<uint2*>(q) = p1;
+        *reinterpret_cast<uint2*>(q + 32) = p2;
+        *reinterpret_cast<uint2*>(q + 64) = p3;
+      } else {
+        uint2 p1, p2;
+        split2h_quad(v, (float)(1 << X2H_KX), p1, p2);
+        *reinterpret_cast<uint2*>(q) = p1;
+        *reinterpret_cast<uint2*>(q + 32) = p2;
+      }
     }
   };
-  bf16x8 fb[2][TN][3];
+  bf16x8 fb[2][TN][NP];
   int lw_kc = 0, lw_t = 0;            // the next weight chunk to load
   auto load_w = [&](auto S) {         // chunk parity S: odd chunks come from the sign-flipped copy
     constexpr int s_ = decltype(S)::value;
@@ -1333,8 +1368,8 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) {
-        const unsigned off = (unsigned)(((c * J + jt0 + b) * 3 + p) * 1024) + lane16 + (s_ ? neg_off : 0u);
+      for (int p = 0; p < NP; ++p) {
+        const unsigned off = (unsigned)(((c * J + jt0 + b) * NP + p) * 1024) + lane16 + (s_ ? neg_off : 0u);
         fb[s_][b][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
       }
     if (lw_kc * 9 + lw_t + 1 < nch) { lw_t += 1; if (lw_t == 9) { lw_t = 0; lw_kc += 1; } }
@@ -1358,28 +1393,36 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
   if (kch > 1) load_halo(1);
   __syncthreads();
 
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-  bf16x8 fa[TM][3];
-  const unsigned char* Abase = sm + ((wm * 2 + 1) * HWD + l31 + 1) * X3_ROWB + h * 16;
+  constexpr int NTERM = NP == 3 ? 6 : 3;
+  constexpr int PA[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};       // smallest products first
+  constexpr int PB[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
+  bf16x8 fa[TM][NP];
+  const unsigned char* Abase = sm + ((wm * 2 + 1) * HWD + l31 + 1) * ROWB + h * 16;
   int kc = 0, t = 0;
   auto step = [&](auto PAR) {
     constexpr int par = decltype(PAR)::value;
     const unsigned char* Ab = Abase + s_ho[t];
 #pragma unroll
-    for (int o = 0; o < 3; ++o) {
-      const int pa = o == 0 ? 0 : (o == 1 ? 2 : 1);
+    for (int o = 0; o < NP; ++o) {
+      const int pa = NP == 3 ? (o == 0 ? 0 : (o == 1 ? 2 : 1)) : (1 - o);
 #pragma unroll
-      for (int a = 0; a < TM; ++a) fa[a][pa] = *reinterpret_cast<const bf16x8*>(Ab + a * HWD * X3_ROWB + pa * 32);
+      for (int a = 0; a < TM; ++a) fa[a][pa] = *reinterpret_cast<const bf16x8*>(Ab + a * HWD * ROWB + pa * 32);
     }
     load_w(std::integral_constant<int, 1 - par>{});                 // the next chunk's weight fragments
 #pragma unroll
-    for (int term = 0; term < 6; ++term)
+    for (int term = 0; term < NTERM; ++term)
 #pragma unroll
       for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          acc[par][a][b] =
-              __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[par][b][PB[term]], acc[par][a][b], 0, 0, 0);
+        for (int b = 0; b < TN; ++b) {
+          if constexpr (NP == 3)
+            acc[par][a][b] =
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[par][b][PB[term]], acc[par][a][b], 0, 0, 0);
+          else
+            acc[par][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a][PA[term]]),
+                                                                    __builtin_bit_cast(f16x8, fb[par][b][PB[term]]),
+                                                                    acc[par][a][b], 0, 0, 0);
+        }
     t += 1;
     if (t == 9) {
       t = 0; kc += 1;
@@ -1400,7 +1443,10 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][a][b][r] -= acc[1][a][b][r];
+      for (int r = 0; r < 16; ++r) {
+        acc[0][a][b][r] -= acc[1][a][b][r];
+        if constexpr (NP == 2) acc[0][a][b][r] *= 1.f / (float)(1 << (X2H_KX + X2H_KW));      // exact
+      }
   __syncthreads();                         // the halo is dead: the epilogue reuses its LDS
 
   conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
@@ -1433,6 +1479,35 @@ __global__ void split_weight_frag_kernel(const float* __restrict__ w, u32x4* __r
   const u32x4 f = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
   out[base] = q1; out[base + 64] = q2; out[base + 128] = q3;
   out[units + base] = q1 ^ f; out[units + base + 64] = q2 ^ f; out[units + base + 128] = q3 ^ f;
+}
+
+// The fp16 two-piece form of the same image (conv3x3_x3w_body<.., NP = 2>): unit (((c*J + j)*2 + p)*2 + h)*32 + r, pieces of
+// w * 2^X2H_KW; the sign-flipped copy follows (an fp16 sign bit sits where a bf16 one does).
+__global__ void split_weight_frag_h2_kernel(const float* __restrict__ w, u32x4* __restrict__ out, const int rows,
+                                            const int wstride, const int J, const long long units) {
+  const long long u = (long long)blockIdx.x * blockDim.x + threadIdx.x;       // (c, j, h, r): one thread writes 2 pieces
+  const long long nthreads = (long long)(wstride >> 4) * J * 64;
+  if (u >= nthreads) return;
+  const int r = (int)(u & 31), hh = (int)((u >> 5) & 1);
+  const long long cj = u >> 6;
+  const int j = (int)(cj % J);
+  const long long c = cj / J;
+  const int row = 32 * j + r;
+  u32x4 q1 = {0, 0, 0, 0}, q2 = q1;
+  if (row < rows) {
+    const float* src = w + (long long)row * wstride + c * 16 + hh * 8;
+    const float4 v0 = ld4(src), v1 = ld4(src + 4);
+    const float sc = (float)(1 << X2H_KW);
+    uint2 a1, a2, b1, b2;
+    split2h_quad(v0, sc, a1, a2);
+    split2h_quad(v1, sc, b1, b2);
+    q1.x = a1.x; q1.y = a1.y; q1.z = b1.x; q1.w = b1.y;
+    q2.x = a2.x; q2.y = a2.y; q2.z = b2.x; q2.w = b2.y;
+  }
+  const long long base = ((cj * 2) * 2 + hh) * 32 + r;
+  const u32x4 f = {0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};
+  out[base] = q1; out[base + 64] = q2;
+  out[units + base] = q1 ^ f; out[units + base + 64] = q2 ^ f;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1491,23 +1566,23 @@ void conv_gather_x3_multi_kernel(const GatherMulti P) {
                                     s.bnb, s.pro, BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
 }
 
-template <int BN, int TH>
+template <int BN, int TH, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_x3w_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
                         float* __restrict__ dst, const DcsConvGeom g, const int accumulate, const int ntiles,
                         float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
                         const unsigned neg_off) {
-  conv3x3_x3w_body<BN, TH>(src, wfrag, bias, dst, g, accumulate, ntiles, stats, bnb, pro, J, neg_off, DCS_BLK);
+  conv3x3_x3w_body<BN, TH, NP>(src, wfrag, bias, dst, g, accumulate, ntiles, stats, bnb, pro, J, neg_off, DCS_BLK);
 }
-template <int BN, int TH>
+template <int BN, int TH, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv3x3_x3w_multi_kernel(const GatherMulti P) {
   const int lv = multi_level(P);
   const GatherSub& s = P.s[lv];
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
-  conv3x3_x3w_body<BN, TH>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.bnb, s.pro, s.J, s.neg_off,
-                           BlkId{rel, s.nbx, 0});
+  conv3x3_x3w_body<BN, TH, NP>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.bnb, s.pro, s.J, s.neg_off,
+                               BlkId{rel, s.nbx, 0});
 }
 
 template <int BT>
@@ -1584,7 +1659,7 @@ extern "C" int dcs_split_weight(const float* w, void* out, int64_t rows, int wst
 namespace {
 
 // ---- launch plans: validation + kernel choice of one (sub-)launch, shared by the single and the multi entries -----------
-enum GatherKid { GK_X3W_64, GK_X3W_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64 };
+enum GatherKid { GK_X3W_64, GK_X3W_128, GK_X2H_64, GK_X2H_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64 };
 struct GatherPlan { int kid; DcsConvGeom g; GatherSub s; unsigned nbx, nby; };
 
 int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
@@ -1667,7 +1742,9 @@ int plan_x3w(const DcsGatherLaunch& a, GatherPlan& P) {
     if (geom->wofs[t] & 15) return DCS_E_UNSUPPORTED;
   if ((long long)geom->SH * geom->SW * geom->src_cstride * 4 > 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
   const BnBwdEpi bnb{a.bn_y, a.bn_mask, a.bn, a.relu};
-  DCS_CHECK_ARG(!(a.stats && a.accumulate && !bnb.y));
+  const bool accum = (a.accumulate & 1) != 0, h2 = (a.accumulate & DCS_ACC_FP16X2) != 0;
+  DCS_CHECK_ARG((a.accumulate & ~(1 | DCS_ACC_FP16X2)) == 0);
+  DCS_CHECK_ARG(!(a.stats && accum && !bnb.y));
   DCS_CHECK_ARG(!a.pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(a.pro)));
   DCS_CHECK_ARG(!bnb.y || (a.stats && bnb.bn && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
                            dcs_aligned16(a.dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
@@ -1675,12 +1752,12 @@ int plan_x3w(const DcsGatherLaunch& a, GatherPlan& P) {
   DCS_CHECK_ARG(M < 0x7FFFFF00ll);
   const int ntiles = (geom->Cout + bn_ - 1) / bn_;
   const int J = (geom->Cout + 31) / 32;
-  const long long units = (long long)(geom->wstride >> 4) * J * 3 * 64;
+  const long long units = (long long)(geom->wstride >> 4) * J * (h2 ? 2 : 3) * 64;
   P.g = *geom;
   P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), a.bias, a.dst, a.stats, a.pro, bnb, 0ll,
-                  (a.accumulate ? 1 : 0) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), ntiles, 0, J,
+                  (accum ? 1 : 0) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), ntiles, 0, J,
                   (unsigned)(units * 16), 0, 0, 0};
-  P.kid = bn_ == 64 ? GK_X3W_64 : GK_X3W_128;
+  P.kid = h2 ? (bn_ == 64 ? GK_X2H_64 : GK_X2H_128) : (bn_ == 64 ? GK_X3W_64 : GK_X3W_128);
   P.nbx = (unsigned)((M / (bn_ == 64 ? 256 : 128)) * ntiles);
   P.nby = 1;
   return DCS_OK;
@@ -1695,6 +1772,12 @@ int launch_gather_one(const GatherPlan& P, hipStream_t s) {
       break;
     case GK_X3W_128:
       hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      break;
+    case GK_X2H_64:
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      break;
+    case GK_X2H_128:
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
       break;
     case GK_HALO_64:
       hipLaunchKernelGGL((conv3x3_x3_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro);
@@ -1756,6 +1839,8 @@ int launch_gather_multi(const GatherPlan* const* plans, int n, hipStream_t s) {
   switch (plans[0]->kid) {
     case GK_X3W_64: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<64, 8>), grid, blk, 0, s, mp); break;
     case GK_X3W_128: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4>), grid, blk, 0, s, mp); break;
+    case GK_X2H_64: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<64, 8, 2>), grid, blk, 0, s, mp); break;
+    case GK_X2H_128: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4, 2>), grid, blk, 0, s, mp); break;
     case GK_STEM_256: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, true>), grid, blk, 0, s, mp); break;
     case GK_STEM_128: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, true>), grid, blk, 0, s, mp); break;
     case GK_128: hipLaunchKernelGGL(conv_gather_x3_multi_kernel<128>, grid, blk, 0, s, mp); break;
@@ -1939,6 +2024,17 @@ extern "C" int dcs_split_weight_frag(const float* w, void* out, int64_t rows, in
   const long long nthreads = (long long)(wstride >> 4) * J * 64;
   DCS_CHECK_ARG(units * 32 < 0x7FFFFFFFll);
   hipLaunchKernelGGL(split_weight_frag_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, dcs_stream(stream), w,
+                     reinterpret_cast<u32x4*>(out), (int)rows, wstride, J, units);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_split_weight_frag_h2(const float* w, void* out, int64_t rows, int wstride, void* stream) {
+  DCS_CHECK_ARG(w && out && rows > 0 && wstride > 0 && (wstride & 15) == 0 && dcs_aligned16(w) && dcs_aligned16(out));
+  const int J = (int)((rows + 31) / 32);
+  const long long units = (long long)(wstride >> 4) * J * 2 * 64;
+  const long long nthreads = (long long)(wstride >> 4) * J * 64;
+  DCS_CHECK_ARG(units * 32 < 0x7FFFFFFFll);
+  hipLaunchKernelGGL(split_weight_frag_h2_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, dcs_stream(stream), w,
                      reinterpret_cast<u32x4*>(out), (int)rows, wstride, J, units);
   DCS_LAUNCH_RET();
 }

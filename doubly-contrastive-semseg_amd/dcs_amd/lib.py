@@ -57,6 +57,7 @@ SIGNATURES = {
     "dcs_split_weight": [_P, _P, _L, _I, _P],
     "dcs_conv_gather_x3": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P],
     "dcs_split_weight_frag": [_P, _P, _L, _I, _P],
+    "dcs_split_weight_frag_h2": [_P, _P, _L, _I, _P],
     "dcs_conv3x3_x3w": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _P],
     "dcs_conv_wgrad_x3": [_P, _P, _P, _G, _I, _I, _I, _P, _P],
     "dcs_conv_gather_x3_multi": [C.POINTER(DcsGatherLaunch), _I, _P],

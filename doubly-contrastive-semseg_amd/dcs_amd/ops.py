@@ -428,6 +428,31 @@ def split_weight_frag(wk):
     return out
 
 
+ACC_FP16X2 = 16          # DCS_ACC_FP16X2 (include/dcs_hip.h)
+
+
+def split_weight_frag_h2(wk):
+    """The fp16 two-piece form of split_weight_frag (forward 3x3 convolutions, three MFMAs per product): cached per step."""
+    key = ("frag_h2", wk.data_ptr(), tuple(wk.shape), tuple(wk.stride()))
+    hit = _split_cache.get(key)
+    if hit is not None:
+        return hit[1]
+    rows = wk.shape[0]
+    ws = wk.numel() // rows
+    J = -(-rows // 32)
+    out = torch.empty((2 * (ws // 16) * J * 2 * 256,), device=wk.device, dtype=_F32)
+    _call_now("dcs_split_weight_frag_h2", _p(wk), _p(out), rows, ws, _stream())
+    if len(_split_cache) >= 1024:
+        _split_cache.clear()
+    _split_cache[key] = (wk, out)
+    return out
+
+
+def x2h_on():
+    """Forward 3x3 convolutions on two fp16 pieces (DCS_X2H=0: three bf16 pieces like the data gradients)."""
+    return os.environ.get("DCS_X2H", "1") != "0"
+
+
 def x3w_ok(g):
     """Dense 3x3 / stride 1 launches (8 x 32-pixel tiles of <= 64 channels, 4 x 32 of 128) with at least 256 tiles run
     the halo-resident kernel that takes its weight fragments straight from global memory (csrc/conv_split.hip,
@@ -447,12 +472,17 @@ def x3w_ok(g):
     return ok and os.environ.get("DCS_X3W", "1") != "0" and os.environ.get("DCS_X3_HALO", "1") == "1"
 
 
-def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None, ns=1, slab_n=0):
-    """One launch of the gather kernel family.  bnb = (y, mask, bn record, relu) or None."""
+def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None, ns=1, slab_n=0, fwd=False):
+    """One launch of the gather kernel family.  bnb = (y, mask, bn record, relu) or None.  fwd: a forward convolution
+    (activations x weights: operands of known magnitude -> the fp16 two-piece kernel where it applies)."""
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
     if ns == 1 and x3_ok(g) and x3w_ok(g):
-        _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
-              _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _stream())
+        if fwd and x2h_on():
+            _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
+                  _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _stream())
+        else:
+            _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
+                  _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _stream())
     elif x3_ok(g):
         _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
               _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _stream())
@@ -478,7 +508,7 @@ def _gather_split(src, wgt, g, ns, dst, accumulate, pro=None):
 
 
 def _gather(src, wgt, bias, dst, g, accumulate, stats, pro):
-    _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro)
+    _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro, fwd=True)
 
 
 def pro_ok(Cin):

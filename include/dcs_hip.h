@@ -129,8 +129,14 @@ int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, 
  * from global memory into the MFMA fragments: dcs_split_weight_frag lays them out fragment-major (unit
  * (((c*J + j)*3 + p)*2 + h)*32 + r of 16 bytes = piece p of row 32j + r, channels 16c + 8h .. +7, J = ceil(rows / 32)),
  * followed by a sign-flipped copy (2 x wstride/16 x J x 3 KiB in all); dcs_conv3x3_x3w is dcs_conv_gather_x3 (one K
- * split) on that layout.  Other geometries: DCS_E_UNSUPPORTED. */
+ * split) on that layout.  Other geometries: DCS_E_UNSUPPORTED.
+ * accumulate | DCS_ACC_FP16X2 (forward convolutions): the operands are split into TWO fp16 pieces instead of three bf16
+ * ones -- three MFMAs per product instead of six; activations scaled by 2^2, weights by 2^10 (exact), i.e. defined for
+ * |x| < 16384 and |w| < 64 (beyond: inf, like any fp16 conversion), same fp32-class error (csrc/conv_split.hip, split2h_quad).
+ * wfrag must then come from dcs_split_weight_frag_h2 (unit (((c*J + j)*2 + p)*2 + h)*32 + r; 2 x wstride/16 x J x 2 KiB). */
+#define DCS_ACC_FP16X2 16
 int dcs_split_weight_frag(const float* w, void* out, int64_t rows, int wstride, void* stream);
+int dcs_split_weight_frag_h2(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, float* dst, const DcsConvGeom* geom,
                     int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
                     const float* bn, int relu, void* stream);

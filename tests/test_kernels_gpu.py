@@ -701,6 +701,51 @@ def test_split_bf16_convolution_has_fp32_class_error(ops, monkeypatch, N, H, W, 
     assert e_x3 <= 1.5 * e_32 + 1e-7
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 64, 64, 64), (4, 16, 64, 128, 128), (2, 8, 96, 256, 128), (2, 8, 64, 128, 256),
+                                             (1, 16, 32, 512, 512)])
+def test_fp16_two_piece_forward_convolution_has_fp32_class_error(ops, monkeypatch, N, H, W, Cin, Cout):
+    """Forward 3x3 / stride 1 convolutions run on TWO fp16 pieces per operand (three v_mfma_f32_32x32x16_f16 per product
+    instead of six bf16 ones; conv_split.hip, split2h_quad).  Against a float64 convolution of the same fp32 inputs: error
+    <= 1.5x the exact-fp32 MFMA kernel's (+ floor), no rounding bias, and it must really be another kernel than the three-
+    piece bf16 one (the results differ in the last bits, both within the budget); with the BatchNorm + ReLU prologue and the
+    statistics epilogue; small and large magnitudes inside the documented domain."""
+    monkeypatch.setenv("DCS_KSPLIT", "0")
+    monkeypatch.setenv("DCS_X3W_MIN", "1")                 # the weight-fragment kernel on these small maps
+    x = rnd(N, H, W, Cin, seed=141)
+    x[0, :2] *= 300.0                                       # large activations
+    x[-1, -2:] *= 1e-3                                      # and tiny ones
+    w = cl(rnd(Cout, Cin, 3, 3, seed=142, scale=0.05))
+    w[:3] *= 40.0
+    w[3:6] *= 1e-3
+    ref = E.conv_fwd(x.double(), w.double(), 1, 1)
+    xd, wd = x.to(DEV), cl(w.to(DEV))
+    g = ops.geom_fwd(N, H, W, Cin, Cout, 3, 3, 1, 1)
+    assert ops.x3_ok(g) and ops.x3w_ok(g)
+    got, st = ops.conv_fwd(xd, wd, 1, 1, want_stats=True)
+    got2, st2 = ops.conv_fwd(xd, wd, 1, 1, want_stats=True)
+    assert torch.equal(got, got2) and torch.equal(st, st2)
+    monkeypatch.setenv("DCS_X2H", "0")
+    b3 = ops.conv_fwd(xd, wd, 1, 1)
+    monkeypatch.setenv("DCS_CONV_X3", "0")
+    f32 = ops.conv_fwd(xd, wd, 1, 1)
+    monkeypatch.delenv("DCS_CONV_X3"); monkeypatch.delenv("DCS_X2H")
+    got, b3, f32 = got.cpu(), b3.cpu(), f32.cpu()
+    assert not torch.equal(got, b3)
+    scale = float(ref.abs().max())
+    e_h, e_3, e_32 = (float((t.double() - ref).abs().max()) / scale for t in (got, b3, f32))
+    l_h, l_32 = (float((t.double() - ref).norm() / ref.norm()) for t in (got, f32))
+    print(f"max-rel fp16x2 {e_h:.3e} bf16x3 {e_3:.3e} fp32 {e_32:.3e} | l2-rel fp16x2 {l_h:.3e} fp32 {l_32:.3e}")
+    assert e_h <= 1.5 * e_32 + 1e-7 and l_h <= 1.5 * l_32 + 1e-8
+    err = (got.double() - ref)[:, 3:H - 3, :, 6:]           # the part of ordinary magnitude (equal weights in the bias measure)
+    assert abs(float(err.sum() / err.abs().sum())) < 0.03, float(err.sum() / err.abs().sum())
+    close(st[0, 0], got.reshape(-1, Cout).double().mean(0).float(), 1e-4, "statistics epilogue (mean)")
+    # BatchNorm + ReLU prologue: bitwise the convolution of the materialised activation
+    gam, bet = (rnd(Cin, seed=143) * 0.1 + 1).to(DEV), (rnd(Cin, seed=144) * 0.1).to(DEV)
+    bn = ops.bn_finalize(ops.colsum(xd.reshape(-1, Cin), moments=True), gam, bet, torch.zeros(Cin, device=DEV),
+                         torch.ones(Cin, device=DEV), N * H * W, True)
+    assert torch.equal(ops.conv_fwd(xd, wd, 1, 1, pro=bn), ops.conv_fwd(ops.bn_act(xd, bn, relu=True), wd, 1, 1))
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s", [
     (4, 24, 40, 64, 64, 3, 1), (2, 33, 29, 128, 128, 3, 1), (4, 16, 24, 64, 128, 3, 2), (2, 20, 36, 256, 128, 1, 1),
     (8, 12, 16, 512, 512, 3, 1), (2, 19, 21, 128, 80, 3, 1),
