@@ -227,8 +227,9 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
                          const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
                          float* __restrict__ dy, float* __restrict__ gm_out, float* __restrict__ dgamma,
                          float* __restrict__ dbeta, long long rows, int C, int relu, int acc_dy, int acc_gm,
-                         int acc_param, int training) {
+                         int acc_param, int training, unsigned* __restrict__ dy_maxabs) {
   const int C4 = C >> 2;
+  float mx = 0.f;
   const long long n4 = rows * C4;
   // eval-mode BatchNorm is a fixed affine map: the batch-statistics terms vanish
   const float inv = training ? (float)(1.0 / (double)rows) : 0.f;
@@ -274,6 +275,20 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
       o.w = gi.w * (v.w - t0.w - (yy.w - mu.w) * is.w * t1.w);
       if (acc_dy) { const float4 p = ld4(dy + i * 4); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
       stx4<NT>(dy + i * 4, o);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+  }
+  if (dy_maxabs) {                                         // max of non-negative floats = max of their bit patterns
+    // one candidate per block; the word only grows, so a (possibly stale) plain read that is already >= the candidate
+    // makes the atomic unnecessary: a few dozen same-address atomics per launch instead of thousands (they serialise)
+    __shared__ float s_mx[4];
+    mx = dcs_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+      const unsigned bits = __float_as_uint(mx);
+      if (bits > __hip_atomic_load(dy_maxabs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dy_maxabs, bits);
     }
   }
 }
@@ -442,18 +457,19 @@ extern "C" int dcs_bn_act(const float* y, const float* bn, const float* r, const
 extern "C" int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
                                 const float* gamma, const float* sums, float* dy, float* gm_out, float* dgamma,
                                 float* dbeta, int64_t rows, int C, int relu, int acc_dy, int acc_gm, int acc_param,
-                                int training, void* stream) {
+                                int training, uint32_t* dy_maxabs, void* stream) {
   DCS_CHECK_ARG(g && y && bn && rows > 0 && C > 0 && (C & 3) == 0);
+  DCS_CHECK_ARG(!dy_maxabs || dy);
   DCS_CHECK_ARG(!dy || (gamma && sums));
   DCS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || sums));
   const long long n4 = (long long)rows * (C / 4);
   const bool nt = dcs_streams(n4 * 16);               // >= 256 MiB per tensor: nothing to keep in the caches
   if (nt)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
-                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training);
+                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training, dy_maxabs);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
-                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training);
+                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training, dy_maxabs);
   DCS_LAUNCH_RET();
 }
 

@@ -1267,7 +1267,7 @@ __device__ __forceinline__
 void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
                         float* __restrict__ dst, const DcsConvGeom& g, const int accumulate, const int ntiles,
                         float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
-                        const unsigned neg_off, const BlkId bi) {
+                        const unsigned neg_off, const BlkId bi, const unsigned* __restrict__ src_max = nullptr) {
   constexpr int BM = 32 * TH, HWD = 34, HROWS = (TH + 2) * HWD;
   constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = 2, TN = BN / (WN * 32);
   constexpr int ROWB = NP == 3 ? X3_ROWB : 80;
@@ -1291,6 +1291,17 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
   const bool has_pro = pro != nullptr;
   if (has_pro)
     for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
+  // fp16 two-piece form: scale of the source operand (exact powers of two).  Activations: 2^X2H_KX; a tensor whose
+  // maximum is known (data gradients): the power of two that puts it into [2^13, 2^14)
+  float x2h_in = (float)(1 << X2H_KX), x2h_out = 1.f / (float)(1 << (X2H_KX + X2H_KW));
+  if (NP == 2 && src_max != nullptr) {
+    const unsigned mbits = __builtin_amdgcn_readfirstlane(*src_max);
+    const int e = (int)((mbits >> 23) & 0xffu) - 126;               // max = f 2^e, f in [0.5, 1)
+    int k = (mbits >> 23) == 0u ? 0 : 14 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    x2h_in = __uint_as_float((unsigned)(127 + k) << 23);
+    x2h_out = __uint_as_float((unsigned)(127 - k - X2H_KW) << 23);
+  }
 
   const int bid = dcs_xcd_remap(bi.x, bi.nx);
   const int ntile = bid % ntiles, mtile = bid / ntiles;
@@ -1354,7 +1365,7 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
         *reinterpret_cast<uint2*>(q + 64) = p3;
       } else {
         uint2 p1, p2;
-        split2h_quad(v, (float)(1 << X2H_KX), p1, p2);
+        split2h_quad(v, x2h_in, p1, p2);
         *reinterpret_cast<uint2*>(q) = p1;
         *reinterpret_cast<uint2*>(q + 32) = p2;
       }
@@ -1445,7 +1456,7 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         acc[0][a][b][r] -= acc[1][a][b][r];
-        if constexpr (NP == 2) acc[0][a][b][r] *= 1.f / (float)(1 << (X2H_KX + X2H_KW));      // exact
+        if constexpr (NP == 2) acc[0][a][b][r] *= x2h_out;             // a power of two: exact
       }
   __syncthreads();                         // the halo is dead: the epilogue reuses its LDS
 
@@ -1526,6 +1537,7 @@ struct GatherSub {
   int accumulate, ntiles, cps, J;
   unsigned neg_off;
   int blk0, nbx, nblk;
+  const unsigned* src_max;             // fp16 two-piece kernels: device word with the bits of max |src| (nullable)
 };
 struct GatherMulti { DcsConvGeom g[MULTI_MAX]; GatherSub s[MULTI_MAX]; };
 
@@ -1571,8 +1583,8 @@ __global__ __launch_bounds__(256, 2)
 void conv3x3_x3w_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
                         float* __restrict__ dst, const DcsConvGeom g, const int accumulate, const int ntiles,
                         float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
-                        const unsigned neg_off) {
-  conv3x3_x3w_body<BN, TH, NP>(src, wfrag, bias, dst, g, accumulate, ntiles, stats, bnb, pro, J, neg_off, DCS_BLK);
+                        const unsigned neg_off, const unsigned* __restrict__ src_max) {
+  conv3x3_x3w_body<BN, TH, NP>(src, wfrag, bias, dst, g, accumulate, ntiles, stats, bnb, pro, J, neg_off, DCS_BLK, src_max);
 }
 template <int BN, int TH, int NP = 3>
 __global__ __launch_bounds__(256, 2)
@@ -1582,7 +1594,7 @@ void conv3x3_x3w_multi_kernel(const GatherMulti P) {
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
   conv3x3_x3w_body<BN, TH, NP>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.bnb, s.pro, s.J, s.neg_off,
-                               BlkId{rel, s.nbx, 0});
+                               BlkId{rel, s.nbx, 0}, s.src_max);
 }
 
 template <int BT>
@@ -1756,7 +1768,7 @@ int plan_x3w(const DcsGatherLaunch& a, GatherPlan& P) {
   P.g = *geom;
   P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), a.bias, a.dst, a.stats, a.pro, bnb, 0ll,
                   (accum ? 1 : 0) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), ntiles, 0, J,
-                  (unsigned)(units * 16), 0, 0, 0};
+                  (unsigned)(units * 16), 0, 0, 0, h2 ? a.src_max : nullptr};
   P.kid = h2 ? (bn_ == 64 ? GK_X2H_64 : GK_X2H_128) : (bn_ == 64 ? GK_X3W_64 : GK_X3W_128);
   P.nbx = (unsigned)((M / (bn_ == 64 ? 256 : 128)) * ntiles);
   P.nby = 1;
@@ -1768,16 +1780,20 @@ int launch_gather_one(const GatherPlan& P, hipStream_t s) {
   const dim3 grid(P.nbx, P.nby), blk(256);
   switch (P.kid) {
     case GK_X3W_64:
-      hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                         P.s.src_max);
       break;
     case GK_X3W_128:
-      hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                         P.s.src_max);
       break;
     case GK_X2H_64:
-      hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                         P.s.src_max);
       break;
     case GK_X2H_128:
-      hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off);
+      hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                         P.s.src_max);
       break;
     case GK_HALO_64:
       hipLaunchKernelGGL((conv3x3_x3_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro);
@@ -1983,7 +1999,7 @@ extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const fl
                                   const DcsConvGeom* geom, int accumulate, float* stats, const float* pro,
                                   const float* bn_y, const float* bn_mask, const float* bn, int relu, int nsplit,
                                   int64_t slab_stride, void* stream) {
-  const DcsGatherLaunch a{src, wsplit, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, slab_stride, accumulate, relu, nsplit};
+  const DcsGatherLaunch a{src, wsplit, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, slab_stride, accumulate, relu, nsplit, nullptr};
   GatherPlan P;
   const int rc = plan_gather_x3(a, P);
   return rc != DCS_OK ? rc : launch_gather_one(P, dcs_stream(stream));
@@ -2042,8 +2058,8 @@ extern "C" int dcs_split_weight_frag_h2(const float* w, void* out, int64_t rows,
 // dcs_conv_gather_x3 for dense 3x3 / stride 1 geometries with the weights in dcs_split_weight_frag layout
 extern "C" int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, float* dst, const DcsConvGeom* geom,
                                int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
-                               const float* bn, int relu, void* stream) {
-  const DcsGatherLaunch a{src, wfrag, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, 0, accumulate, relu, 1};
+                               const float* bn, int relu, const uint32_t* src_max, void* stream) {
+  const DcsGatherLaunch a{src, wfrag, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, 0, accumulate, relu, 1, src_max};
   GatherPlan P;
   const int rc = plan_x3w(a, P);
   return rc != DCS_OK ? rc : launch_gather_one(P, dcs_stream(stream));

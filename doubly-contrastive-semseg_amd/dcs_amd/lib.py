@@ -30,7 +30,7 @@ class DcsGatherLaunch(C.Structure):
     _fields_ = [("src", C.c_void_p), ("wgt", C.c_void_p), ("bias", C.c_void_p), ("dst", C.c_void_p),
                 ("geom", C.POINTER(DcsConvGeom)), ("stats", C.c_void_p), ("pro", C.c_void_p), ("bn_y", C.c_void_p),
                 ("bn_mask", C.c_void_p), ("bn", C.c_void_p), ("slab_stride", C.c_int64), ("accumulate", C.c_int32),
-                ("relu", C.c_int32), ("nsplit", C.c_int32)]
+                ("relu", C.c_int32), ("nsplit", C.c_int32), ("src_max", C.c_void_p)]
 
 
 class DcsWgradLaunch(C.Structure):
@@ -58,7 +58,7 @@ SIGNATURES = {
     "dcs_conv_gather_x3": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P],
     "dcs_split_weight_frag": [_P, _P, _L, _I, _P],
     "dcs_split_weight_frag_h2": [_P, _P, _L, _I, _P],
-    "dcs_conv3x3_x3w": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _P],
+    "dcs_conv3x3_x3w": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _P, _P],
     "dcs_conv_wgrad_x3": [_P, _P, _P, _G, _I, _I, _I, _P, _P],
     "dcs_conv_gather_x3_multi": [C.POINTER(DcsGatherLaunch), _I, _P],
     "dcs_conv3x3_x3w_multi": [C.POINTER(DcsGatherLaunch), _I, _P],
@@ -74,7 +74,7 @@ SIGNATURES = {
     "dcs_bn_finalize": [_P, _P, _P, _P, _P, _P, _I, _D, _F, _F, _I, _I, _P],
     "dcs_bn_ema_again": [_P, _P, _P, _I, _D, _F, _F, _P],
     "dcs_bn_act": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "dcs_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P],
+    "dcs_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P],
     "dcs_normalize_pyramid": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "dcs_bn_relu_maxpool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dcs_maxpool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],

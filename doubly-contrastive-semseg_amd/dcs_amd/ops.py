@@ -85,13 +85,14 @@ def _ptr(a):
 
 
 def _gather_struct(a, x3w):
-    if x3w:      # dcs_conv3x3_x3w(src, wfrag, bias, dst, geom, accumulate, stats, pro, bn_y, bn_mask, bn, relu, stream)
-        src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, _ = a
+    if x3w:      # dcs_conv3x3_x3w(src, wfrag, bias, dst, geom, accumulate, stats, pro, bn_y, bn_mask, bn, relu, src_max, stream)
+        src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, smax, _ = a
         ns, slab = 1, 0
     else:        # dcs_conv_gather_x3(..., relu, nsplit, slab_stride, stream)
         src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, ns, slab, _ = a
+        smax = None
     return _lib.DcsGatherLaunch(_ptr(src), _ptr(w), _ptr(bias), _ptr(dst), C.pointer(g), _ptr(stats), _ptr(pro), _ptr(yb),
-                                _ptr(mb), _ptr(bnr), slab, acc, relu, ns)
+                                _ptr(mb), _ptr(bnr), slab, acc, relu, ns, _ptr(smax))
 
 
 def _wgrad_struct(a):
@@ -386,11 +387,26 @@ def x3_ok(g):
 _split_cache = {}
 
 
+_max_pool = {"buf": None, "at": 0}       # device words for per-tensor maxima (bn_bwd -> the fp16 two-piece kernels)
+
+
+def _max_slot(device):
+    """One zeroed uint32 device word (a view into a pool that is re-zeroed once per step / when exhausted)."""
+    mp = _max_pool
+    if mp["buf"] is None or mp["buf"].device != device or mp["at"] >= mp["buf"].numel():
+        mp["buf"] = torch.zeros((1024,), device=device, dtype=torch.int32)
+        mp["at"] = 0
+    s = mp["buf"][mp["at"]:mp["at"] + 1]
+    mp["at"] += 1
+    return s
+
+
 def new_step():
     """Weights may change between steps (optimizer): forget the split images of the previous step.  Called at the start of
     every model forward; within one forward + backward a weight (or its data-gradient repack) is split once and reused
     by the three pyramid levels."""
     _split_cache.clear()
+    _max_pool["buf"] = None
 
 
 def split_weight(wk):
@@ -474,15 +490,17 @@ def x3w_ok(g):
 
 def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None, ns=1, slab_n=0, fwd=False):
     """One launch of the gather kernel family.  bnb = (y, mask, bn record, relu) or None.  fwd: a forward convolution
-    (activations x weights: operands of known magnitude -> the fp16 two-piece kernel where it applies)."""
+    (activations x weights: operands of known magnitude -> the fp16 two-piece kernel where it applies); a data gradient
+    takes that kernel when its source carries the device word with its maximum (bn_bwd's dy: ``_dcs_max``)."""
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
     if ns == 1 and x3_ok(g) and x3w_ok(g):
-        if fwd and x2h_on():
+        smax = None if fwd else getattr(src, "_dcs_max", None)
+        if (fwd or smax is not None) and x2h_on():
             _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
-                  _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _stream())
+                  _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _p(smax), _stream())
         else:
             _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
-                  _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _stream())
+                  _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, None, _stream())
     elif x3_ok(g):
         _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
               _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _stream())
@@ -826,9 +844,16 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
     if want_dy:
         dy = dy_out if dy_out is not None else torch.empty_like(y)
     gm = torch.empty_like(y) if want_gm else None
+    smax = None
+    if dy is not None and y.is_cuda and x2h_on():
+        # the maximum of |dy| rides along (one integer atomicMax per wave): the convolutions that consume dy -- data and
+        # weight gradient -- scale it by an exact power of two into fp16 range (csrc/conv_split.hip, two fp16 pieces)
+        smax = _max_slot(y.device)
     _call("dcs_bn_bwd_apply", _p(g), _p(y), _p(masksrc), _p(bn), _p(gamma), _p(sums), _p(dy), _p(gm), _p(dgamma),
           _p(dbeta), rows, Cc, 1 if relu else 0, 1 if (acc_dy and dy_out is not None) else 0, 0,
-          1 if acc_param else 0, 1 if training else 0, _stream())
+          1 if acc_param else 0, 1 if training else 0, _p(smax), _stream())
+    if smax is not None:
+        dy._dcs_max = smax
     return dy, gm
 
 

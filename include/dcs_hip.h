@@ -133,13 +133,16 @@ int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, 
  * accumulate | DCS_ACC_FP16X2 (forward convolutions): the operands are split into TWO fp16 pieces instead of three bf16
  * ones -- three MFMAs per product instead of six; activations scaled by 2^2, weights by 2^10 (exact), i.e. defined for
  * |x| < 16384 and |w| < 64 (beyond: inf, like any fp16 conversion), same fp32-class error (csrc/conv_split.hip, split2h_quad).
- * wfrag must then come from dcs_split_weight_frag_h2 (unit (((c*J + j)*2 + p)*2 + h)*32 + r; 2 x wstride/16 x J x 2 KiB). */
+ * wfrag must then come from dcs_split_weight_frag_h2 (unit (((c*J + j)*2 + p)*2 + h)*32 + r; 2 x wstride/16 x J x 2 KiB).
+ * src_max (nullable, DCS_ACC_FP16X2 only): device word holding the bit pattern of max |src| (as dcs_bn_bwd_apply's
+ * dy_maxabs leaves it).  The kernel then scales src by the power of two that puts that maximum into [2^13, 2^14) instead of
+ * 2^2: data gradients (src = dy, magnitudes of 1e-3 .. 1e-10) use the same kernel with an exact, per-tensor scale. */
 #define DCS_ACC_FP16X2 16
 int dcs_split_weight_frag(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_split_weight_frag_h2(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, float* dst, const DcsConvGeom* geom,
                     int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
-                    const float* bn, int relu, void* stream);
+                    const float* bn, int relu, const uint32_t* src_max, void* stream);
 
 /* ---- level batching: up to DCS_MULTI_MAX launches of the entries above as ONE grid ---------------------------------------
  * The three pyramid levels of a layer share every weight (network/backbone/resnet_pyramid.py:318-341: the same modules are
@@ -156,6 +159,7 @@ typedef struct DcsGatherLaunch {
   float* stats; const float* pro; const float* bn_y; const float* bn_mask; const float* bn;
   int64_t slab_stride;
   int32_t accumulate, relu, nsplit;
+  const uint32_t* src_max;   /* dcs_conv3x3_x3w with DCS_ACC_FP16X2 only (else null): see there */
 } DcsGatherLaunch;
 int dcs_conv_gather_x3_multi(const DcsGatherLaunch* launches, int n, void* stream);   /* n x dcs_conv_gather_x3 */
 int dcs_conv3x3_x3w_multi(const DcsGatherLaunch* launches, int n, void* stream);      /* n x dcs_conv3x3_x3w (nsplit 1) */
@@ -220,11 +224,14 @@ int dcs_bn_act(const float* y, const float* bn, const float* r, const float* bn2
                int64_t rows, int C, int relu, void* stream);
 /* BN backward apply: gm = g*mask; dy (+)= gamma*invstd*(gm - s0/cnt - xhat*s1/cnt);
  * optional gm_out (+)= gm.  sums = [2][C] from dcs_colsum_* mode 1.  dgamma/dbeta (+)= s1/s0.
- * training = 0 (eval-mode BN, running statistics): dy = gamma*invstd*gm. */
+ * training = 0 (eval-mode BN, running statistics): dy = gamma*invstd*gm.
+ * dy_maxabs (nullable): device word, zero before the call; receives the bit pattern of max |dy| over the written tensor
+ * (integer atomicMax of non-negative floats: order-independent, deterministic) -- the per-tensor scale of the fp16
+ * two-piece convolution kernels that consume dy (dcs_conv3x3_x3w src_max, dcs_conv_wgrad_x3 dy_max). */
 int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
                      const float* gamma, const float* sums, float* dy, float* gm_out,
                      float* dgamma, float* dbeta, int64_t rows, int C, int relu, int acc_dy,
-                     int acc_gm, int acc_param, int training, void* stream);
+                     int acc_gm, int acc_param, int training, uint32_t* dy_maxabs, void* stream);
 
 /* ---- pyramid / pooling / resize -------------------------------------------------------------*/
 /* resnet_pyramid.py:296-314: (x-mean)/std then bicubic 1/2 and 1/4 (A=-0.75, no antialias).
