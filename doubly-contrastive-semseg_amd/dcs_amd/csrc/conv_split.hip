@@ -681,12 +681,16 @@ void conv_wgrad3x3_x3_kernel(const float* __restrict__ src, const float* __restr
 // three rows -- the halo lives in a ring of four row slots (row & 3: the slot of row ty+2 is free while rows ty-1..ty+1 are
 // read).  Only the first chunk of a strip (or of a split) loads three rows, behind two barriers.  Work units are
 // (image, strip, row) in that order; a split is a range of units.
+// NP = 2 (dy_max given): both operands as two fp16 pieces, three MFMAs per product (see split2h_quad): the input is scaled
+// by 2^X2H_KX like in the forward kernels, dy by the power of two that puts its maximum (dy_max: the device word
+// dcs_bn_bwd_apply leaves) into [2^13, 2^14), the slab by the inverse of both.
+template <int NP = 3>
 __device__ __forceinline__
 void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                               const DcsConvGeom& g, const int dy_cstride, const int split0, const int cps, const int ciT,
-                              const float* __restrict__ pro, const BlkId bi) {
+                              const float* __restrict__ pro, const BlkId bi, const unsigned* __restrict__ dy_max = nullptr) {
   constexpr int CHP = 16, HWP = CHP + 2;
-  constexpr int PIECE = 128, ROW = 3 * PIECE + 64;             // 448 = 192 (mod 256)
+  constexpr int PIECE = 128, ROW = NP * PIECE + 64;            // 448 = 192, 320 = 64 (mod 256): conflict-free transposing reads
   constexpr int NSX = (3 * HWP * 16 + 255) / 256;              // 256-thread passes over up to three halo rows
   constexpr int DB = CHP * ROW, XB = 4 * HWP * ROW;            // dy double buffer, ring of four halo rows
   __shared__ __attribute__((aligned(16))) unsigned char sm[2 * DB + XB];
@@ -696,6 +700,15 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int lcol4 = tid & 15, lrow = tid >> 4;
+  float sc_x = (float)(1 << X2H_KX), sc_dy = 1.f, sc_out = 1.f;
+  if (NP == 2) {
+    const unsigned mbits = __builtin_amdgcn_readfirstlane(*dy_max);
+    const int e = (int)((mbits >> 23) & 0xffu) - 126;               // max = f 2^e, f in [0.5, 1)
+    int k = (mbits >> 23) == 0u ? 0 : 14 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    sc_dy = __uint_as_float((unsigned)(127 + k) << 23);
+    sc_out = __uint_as_float((unsigned)(127 - k - X2H_KX) << 23);
+  }
 
   const int ciTile = bi.x % ciT, coTile = bi.x / ciT;
   const int co0 = coTile * 64, ci0 = ciTile * 64;
@@ -749,24 +762,31 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
     }
     ring[s_] = (iy + 4) & 3;
   };
-  auto split_store = [&](float4 v, unsigned char* q) {
-    uint2 p1, p2, p3;
-    split3_quad(v, p1, p2, p3);
-    *reinterpret_cast<uint2*>(q) = p1;
-    *reinterpret_cast<uint2*>(q + PIECE) = p2;
-    *reinterpret_cast<uint2*>(q + 2 * PIECE) = p3;
+  auto split_store = [&](float4 v, unsigned char* q, const float sc) {
+    if constexpr (NP == 3) {
+      uint2 p1, p2, p3;
+      split3_quad(v, p1, p2, p3);
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + PIECE) = p2;
+      *reinterpret_cast<uint2*>(q + 2 * PIECE) = p3;
+    } else {
+      uint2 p1, p2;
+      split2h_quad(v, sc, p1, p2);
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + PIECE) = p2;
+    }
   };
   auto store_slot = [&](auto S, int sl, int buf) {
     constexpr int s_ = decltype(S)::value;
     float4 v = rs[s_][sl];
     if (sl == 0) {
       if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-      split_store(v, sm + buf * DB + lrow * ROW + lcol4 * 8);
+      split_store(v, sm + buf * DB + lrow * ROW + lcol4 * 8, sc_dy);
     } else {
       const int k = sl - 1;
       if (xs_rr[k] != 0) return;
       if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[s_][k]);
-      split_store(v, sm + 2 * DB + (ring[s_] * HWP + xs_hx[k]) * ROW + lcol4 * 8);
+      split_store(v, sm + 2 * DB + (ring[s_] * HWP + xs_hx[k]) * ROW + lcol4 * 8, sc_x);
     }
   };
   // a segment's first unit: dy and rows ty - 1, ty, ty + 1, loaded and stored here and now
@@ -775,7 +795,7 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
       const int off = (((un - n0) * g.TY + uty) * g.TX + utx + lrow) * dy_cstride + cc;
       float4 v = bld4(rsD, ccok ? (unsigned)off * 4u : OOB);
       if (odd) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }
-      split_store(v, sm + buf * DB + lrow * ROW + lcol4 * 8);
+      split_store(v, sm + buf * DB + lrow * ROW + lcol4 * 8, sc_dy);
     }
 #pragma unroll
     for (int k = 0; k < NSX; ++k) {
@@ -785,7 +805,7 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
       const int xoff = (((un - n0) * g.SH + iy) * g.SW + ix) * g.src_cstride + kc;
       float4 v = bld4(rsX, ok ? (unsigned)xoff * 4u : OOB);
       if (has_pro) v = pro_apply(v, p_sc, p_sh, ok ? __builtin_inff() : 0.f);
-      split_store(v, sm + 2 * DB + (((iy + 4) & 3) * HWP + xs_hx[k]) * ROW + lcol4 * 8);
+      split_store(v, sm + 2 * DB + (((iy + 4) & 3) * HWP + xs_hx[k]) * ROW + lcol4 * 8, sc_x);
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -799,7 +819,9 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
 
   const int tj = lane & 15;
   const int tr_off = (8 * h + (tj >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (tj & 3)) * 2;
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int NTERM = NP == 3 ? 6 : 3;
+  constexpr int PA[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};       // smallest products first
+  constexpr int PB[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
   auto frag = [&](const unsigned char* base) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
@@ -827,24 +849,29 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
       const bool has_next = j + 1 < cnt;
       const unsigned char* Db = sm + buf * DB + tr_off + (wm * 32) * 2;
       const unsigned char* Xb = sm + 2 * DB + tr_off + (wn * 32) * 2;
-      bf16x8 fa[3];
+      bf16x8 fa[NP];
 #pragma unroll
-      for (int p = 0; p < 3; ++p) fa[p] = frag(Db + p * PIECE);
+      for (int p = 0; p < NP; ++p) fa[p] = frag(Db + p * PIECE);
       // the input fragments of tap t + 1 are read while tap t multiplies (software pipeline over the unrolled taps)
-      auto load_fb = [&](int t, bf16x8 (&fb)[3]) {
+      auto load_fb = [&](int t, bf16x8 (&fb)[NP]) {
         const int r = t / 3, sx = t % 3;
         const int slot = (c_ty + r + 3) & 3;                            // ring slot of input row c_ty - 1 + r
 #pragma unroll
-        for (int p = 0; p < 3; ++p) fb[p] = frag(Xb + (slot * HWP + sx) * ROW + p * PIECE);
+        for (int p = 0; p < NP; ++p) fb[p] = frag(Xb + (slot * HWP + sx) * ROW + p * PIECE);
       };
-      bf16x8 fbq[2][3];
+      bf16x8 fbq[2][NP];
       load_fb(0, fbq[0]);
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
         if (t + 1 < 9) load_fb(t + 1, fbq[(t + 1) & 1]);
 #pragma unroll
-        for (int term = 0; term < 6; ++term)
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[term]], fbq[t & 1][PB[term]], acc[t], 0, 0, 0);
+        for (int term = 0; term < NTERM; ++term) {
+          if constexpr (NP == 3)
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[term]], fbq[t & 1][PB[term]], acc[t], 0, 0, 0);
+          else
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[PA[term]]),
+                                                            __builtin_bit_cast(f16x8, fbq[t & 1][PB[term]]), acc[t], 0, 0, 0);
+        }
         if (t < 3) {                    // row j + 1 (loaded two iterations ago): registers -> LDS in the shadow of the MFMAs
           if (has_next) store_slot(P, t, buf ^ 1);
           if (t == 2) prefetch(P, sn, stx, c_ty + 3, j + 3 < cnt);       // row j + 3 into the freed set
@@ -869,7 +896,7 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < g.Cout) out[(long long)co * g.wstride + t * g.K + ci] = odd ? -acc[t][r] : acc[t][r];
+        if (co < g.Cout) out[(long long)co * g.wstride + t * g.K + ci] = (odd ? -acc[t][r] : acc[t][r]) * (NP == 2 ? sc_out : 1.f);
       }
   }
 }
@@ -1546,6 +1573,7 @@ struct WgradSub {
   long long mps;
   int dy_cstride, split0, cps, ciT;
   int blk0, nbx, nblk;
+  const unsigned* dy_max;              // fp16 two-piece rolling kernel: device word with the bits of max |dy| (else null)
 };
 struct WgradMulti { DcsConvGeom g[MULTI_MAX]; WgradSub s[MULTI_MAX]; };
 
@@ -1615,20 +1643,22 @@ void conv_wgrad_x3_multi_kernel(const WgradMulti P) {
                          BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
 }
 
+template <int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                               const DcsConvGeom g, const int dy_cstride, const int split0, const int cps, const int ciT,
-                              const float* __restrict__ pro) {
-  conv_wgrad3x3_x3r_body(src, dy, slab, g, dy_cstride, split0, cps, ciT, pro, DCS_BLK);
+                              const float* __restrict__ pro, const unsigned* __restrict__ dy_max) {
+  conv_wgrad3x3_x3r_body<NP>(src, dy, slab, g, dy_cstride, split0, cps, ciT, pro, DCS_BLK, dy_max);
 }
+template <int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad3x3_x3r_multi_kernel(const WgradMulti P) {
   const int lv = multi_level(P);
   const WgradSub& s = P.s[lv];
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
-  conv_wgrad3x3_x3r_body(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.cps, s.ciT, s.pro,
-                         BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
+  conv_wgrad3x3_x3r_body<NP>(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.cps, s.ciT, s.pro,
+                             BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.dy_max);
 }
 
 __global__ __launch_bounds__(256, 2)
@@ -1887,7 +1917,7 @@ int launch_gather_plans(const GatherPlan* plans, int n, hipStream_t s) {
   return DCS_OK;
 }
 
-enum WgradKid { WK_STEM, WK_ROLL, WK_NINE, WK_128, WK_64 };
+enum WgradKid { WK_STEM, WK_ROLL, WK_ROLL_H2, WK_NINE, WK_128, WK_64 };
 struct WgradPlan { int kid; DcsConvGeom g; WgradSub s; unsigned nbx, nby; };
 
 int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
@@ -1900,7 +1930,7 @@ int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
   DCS_CHECK_ARG(geom->dsy == 1 && geom->dsx == 1 && geom->dy0 == 0 && geom->dx0 == 0 &&
                 geom->TY == geom->DH && geom->TX == geom->DW);
   P.g = *geom;
-  P.s = WgradSub{a.src, a.dy, a.slab, a.pro, 0ll, dy_cstride, split0, 0, 0, 0, 0, 0};
+  P.s = WgradSub{a.src, a.dy, a.slab, a.pro, 0ll, dy_cstride, split0, 0, 0, 0, 0, 0, nullptr};
   P.nby = (unsigned)nsplit;
   if (geom->stem) {                    // the seven-tap stem geometry (ops.geom_stem): its own kernel
     if ((geom->TX & 15) || geom->Cout != 64 || geom->wstride != 224 || geom->ntaps != 7 || a.pro) return DCS_E_UNSUPPORTED;
@@ -1931,7 +1961,8 @@ int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
       const long long xbytes = imgs * geom->SH * geom->SW * geom->src_cstride * 4;
       const long long dbytes = imgs * geom->TY * geom->TX * dy_cstride * 4;
       if (dcs_config().wgrad_roll != 0 && xbytes < 0x7FFFFFFFll && dbytes < 0x7FFFFFFFll) {
-        P.kid = WK_ROLL;
+        P.kid = a.dy_max ? WK_ROLL_H2 : WK_ROLL;                    // dy_max: the fp16 two-piece form (this kernel only)
+        P.s.dy_max = a.dy_max;
         return DCS_OK;
       }
     }
@@ -1953,7 +1984,8 @@ int launch_wgrad_one(const WgradPlan& P, hipStream_t s) {
   const dim3 grid(P.nbx, P.nby), blk(256);
   switch (P.kid) {
     case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps); break;
-    case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro); break;
+    case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel<3>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro, nullptr); break;
+    case WK_ROLL_H2: hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel<2>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro, P.s.dy_max); break;
     case WK_NINE: hipLaunchKernelGGL(conv_wgrad3x3_x3_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro); break;
     case WK_128: hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro); break;
     default: hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro);
@@ -1968,7 +2000,8 @@ int launch_wgrad_multi(const WgradPlan* const* plans, int n, hipStream_t s) {
   const dim3 grid((unsigned)total), blk(256);
   switch (plans[0]->kid) {
     case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_multi_kernel, grid, blk, 0, s, mp); break;
-    case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_multi_kernel, grid, blk, 0, s, mp); break;
+    case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_multi_kernel<3>, grid, blk, 0, s, mp); break;
+    case WK_ROLL_H2: hipLaunchKernelGGL(conv_wgrad3x3_x3r_multi_kernel<2>, grid, blk, 0, s, mp); break;
     case WK_128: hipLaunchKernelGGL(conv_wgrad_x3_multi_kernel<128>, grid, blk, 0, s, mp); break;
     case WK_64: hipLaunchKernelGGL(conv_wgrad_x3_multi_kernel<64>, grid, blk, 0, s, mp); break;
     default: return DCS_E_ARG;
@@ -2016,8 +2049,8 @@ extern "C" int dcs_conv_gather_x3_multi(const DcsGatherLaunch* launches, int n, 
 }
 
 extern "C" int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
-                                 int split0, int nsplit, const float* pro, void* stream) {
-  const DcsWgradLaunch a{src, dy, slab, geom, pro, dy_cstride, split0, nsplit};
+                                 int split0, int nsplit, const float* pro, const uint32_t* dy_max, void* stream) {
+  const DcsWgradLaunch a{src, dy, slab, geom, pro, dy_cstride, split0, nsplit, dy_max};
   WgradPlan P;
   const int rc = plan_wgrad_x3(a, P);
   return rc != DCS_OK ? rc : launch_wgrad_one(P, dcs_stream(stream));

@@ -36,7 +36,8 @@ class DcsGatherLaunch(C.Structure):
 class DcsWgradLaunch(C.Structure):
     """One sub-launch of dcs_conv_wgrad_x3_multi."""
     _fields_ = [("src", C.c_void_p), ("dy", C.c_void_p), ("slab", C.c_void_p), ("geom", C.POINTER(DcsConvGeom)),
-                ("pro", C.c_void_p), ("dy_cstride", C.c_int32), ("split0", C.c_int32), ("nsplit", C.c_int32)]
+                ("pro", C.c_void_p), ("dy_cstride", C.c_int32), ("split0", C.c_int32), ("nsplit", C.c_int32),
+                ("dy_max", C.c_void_p)]
 
 
 _P = C.c_void_p
@@ -59,7 +60,7 @@ SIGNATURES = {
     "dcs_split_weight_frag": [_P, _P, _L, _I, _P],
     "dcs_split_weight_frag_h2": [_P, _P, _L, _I, _P],
     "dcs_conv3x3_x3w": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _P, _P],
-    "dcs_conv_wgrad_x3": [_P, _P, _P, _G, _I, _I, _I, _P, _P],
+    "dcs_conv_wgrad_x3": [_P, _P, _P, _G, _I, _I, _I, _P, _P, _P],
     "dcs_conv_gather_x3_multi": [C.POINTER(DcsGatherLaunch), _I, _P],
     "dcs_conv3x3_x3w_multi": [C.POINTER(DcsGatherLaunch), _I, _P],
     "dcs_conv_wgrad_x3_multi": [C.POINTER(DcsWgradLaunch), _I, _P],

@@ -96,8 +96,8 @@ def _gather_struct(a, x3w):
 
 
 def _wgrad_struct(a):
-    src, dy, slab, g, dcs, split0, ns, pro, _ = a      # dcs_conv_wgrad_x3(src, dy, slab, geom, dy_cstride, split0, nsplit, pro, stream)
-    return _lib.DcsWgradLaunch(_ptr(src), _ptr(dy), _ptr(slab), C.pointer(g), _ptr(pro), dcs, split0, ns)
+    src, dy, slab, g, dcs, split0, ns, pro, dmax, _ = a      # dcs_conv_wgrad_x3(src, dy, slab, geom, dy_cstride, split0, nsplit, pro, dy_max, stream)
+    return _lib.DcsWgradLaunch(_ptr(src), _ptr(dy), _ptr(slab), C.pointer(g), _ptr(pro), dcs, split0, ns, _ptr(dmax))
 
 
 class _LevelBatch:
@@ -684,7 +684,9 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
         x3 = M >= 64 * ns
     if x3:
         slab = torch.empty((ns, n), device=x.device, dtype=_F32)
-        _call("dcs_conv_wgrad_x3", _p(x), _p(dy), _p(slab), g, dy.shape[3], 0, ns, _p(pro), _stream())
+        # dy out of bn_bwd carries the device word with its maximum: the rolling 3x3 kernel then runs on two fp16 pieces
+        dmax = getattr(dy, "_dcs_max", None) if x2h_on() else None
+        _call("dcs_conv_wgrad_x3", _p(x), _p(dy), _p(slab), g, dy.shape[3], 0, ns, _p(pro), _p(dmax), _stream())
     else:
         if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 32 == 0:
             tiles = (-(-Cout // 64)) * (-(-Cin // 64))          # nine-tap kernel: one block per 64x64 tile and split
@@ -743,7 +745,7 @@ def stem_wgrad(p, dy, dwp, accumulate):
         ns = max(2, min(512, M // 64))
         ns += ns & 1
         slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
-        _call("dcs_conv_wgrad_x3", _p(p), _p(dy), _p(slab), g, 64, 0, ns, None, _stream())
+        _call("dcs_conv_wgrad_x3", _p(p), _p(dy), _p(slab), g, 64, 0, ns, None, None, _stream())
         _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, 0, 0, _stream())
         return
     ns = max(1, min(512, M // 64)) if g.DW % 32 == 0 else _nsplit(7, M)   # seven-row stem kernel: one block per split

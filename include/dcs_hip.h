@@ -167,12 +167,16 @@ int dcs_conv3x3_x3w_multi(const DcsGatherLaunch* launches, int n, void* stream);
 /* dcs_conv_wgrad / dcs_conv_wgrad_pro (pro nullable) on the bf16 matrix cores, operands as three bf16 pieces; slabs of
  * odd split index carry the hardware's rounding bias with the opposite sign, so an EVEN nsplit cancels it in
  * dcs_reduce_slab.  Cout % 4 == 0; the stem in its seven-tap form with TX % 16 == 0, Cout 64, wstride 224, no prologue
- * (else DCS_E_UNSUPPORTED). */
+ * (else DCS_E_UNSUPPORTED).
+ * dy_max (nullable): the device word dcs_bn_bwd_apply left with the bits of max |dy|.  With it, dense 3x3 / stride 1
+ * geometries that take the rolling-window kernel run on TWO fp16 pieces per operand (three MFMAs per product; the input
+ * scaled by 2^2, dy by the power of two that puts its maximum into [2^13, 2^14), both exact); other geometries ignore it. */
 int dcs_conv_wgrad_x3(const float* src, const float* dy, float* slab, const DcsConvGeom* geom, int dy_cstride,
-                      int split0, int nsplit, const float* pro, void* stream);
+                      int split0, int nsplit, const float* pro, const uint32_t* dy_max, void* stream);
 typedef struct DcsWgradLaunch {
   const float* src; const float* dy; float* slab; const DcsConvGeom* geom; const float* pro;
   int32_t dy_cstride, split0, nsplit;
+  const uint32_t* dy_max;
 } DcsWgradLaunch;
 int dcs_conv_wgrad_x3_multi(const DcsWgradLaunch* launches, int n, void* stream);     /* n x dcs_conv_wgrad_x3, see above */
 

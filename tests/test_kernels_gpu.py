@@ -783,6 +783,48 @@ def test_fp16_two_piece_data_gradient_scales_by_the_tensor_maximum(ops, monkeypa
     assert e_h <= 1.5 * e_32 + 1e-7 and l_h <= 1.5 * l_32 + 1e-8
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,mag", [(4, 16, 64, 64, 64, 1e-6), (4, 16, 32, 128, 128, 3e-9), (8, 8, 32, 256, 128, 2e-3),
+                                                 (2, 16, 48, 128, 256, 40.0)])
+def test_fp16_two_piece_weight_gradient(ops, monkeypatch, N, H, W, Cin, Cout, mag):
+    """Weight gradients of 3x3 / stride 1 convolutions on two fp16 pieces (rolling-window kernel; dy out of bn_bwd with its
+    maximum word, the input with the BatchNorm + ReLU prologue): error vs a float64 weight gradient <= 1.5x the exact-fp32
+    kernels', no rounding bias, deterministic, another kernel than the bf16 one."""
+    g = rnd(N, H, W, Cout, seed=161) * mag
+    g.view(-1)[::997] *= 1000.0
+    yb = rnd(N, H, W, Cout, seed=162)
+    gam, bet = (rnd(Cout, seed=163) * 0.1 + 1).to(DEV), (rnd(Cout, seed=164) * 0.1).to(DEV)
+    ybd = yb.to(DEV)
+    bn_o = ops.bn_finalize(ops.colsum(ybd.reshape(-1, Cout), moments=True), gam, bet, torch.zeros(Cout, device=DEV),
+                           torch.ones(Cout, device=DEV), N * H * W, True)
+    dy, _ = ops.bn_bwd(g.to(DEV), ybd, bn_o, gam, relu=True)
+    assert hasattr(dy, "_dcs_max")
+    x = rnd(N, H, W, Cin, seed=165)
+    xd = x.to(DEV)
+    gi, bi_ = (rnd(Cin, seed=166) * 0.1 + 1).to(DEV), (rnd(Cin, seed=167) * 0.1).to(DEV)
+    bn_i = ops.bn_finalize(ops.colsum(xd.reshape(-1, Cin), moments=True), gi, bi_, torch.zeros(Cin, device=DEV),
+                           torch.ones(Cin, device=DEV), N * H * W, True)
+    act = ops.bn_act(xd, bn_i, relu=True)
+    ref = cl(torch.empty(Cout, Cin, 3, 3, dtype=torch.float64))
+    E.conv_wgrad(act.cpu().double(), dy.cpu().double(), ref, 1, 1, False)
+    got, got2, b3, f32 = (cl(torch.empty(Cout, Cin, 3, 3, device=DEV)) for _ in range(4))
+    ops.conv_wgrad(xd, dy, got, 1, 1, False, pro=bn_i)
+    ops.conv_wgrad(xd, dy, got2, 1, 1, False, pro=bn_i)
+    monkeypatch.setenv("DCS_X2H", "0")
+    ops.conv_wgrad(xd, dy, b3, 1, 1, False, pro=bn_i)
+    monkeypatch.setenv("DCS_CONV_X3", "0")
+    ops.conv_wgrad(xd, dy, f32, 1, 1, False, pro=bn_i)
+    monkeypatch.delenv("DCS_CONV_X3"); monkeypatch.delenv("DCS_X2H")
+    assert torch.equal(got, got2) and not torch.equal(got, b3)
+    scale = float(ref.abs().max())
+    err = got.cpu().double() - ref
+    e_h, e_3, e_32 = float(err.abs().max()) / scale, float((b3.cpu().double() - ref).abs().max()) / scale, \
+        float((f32.cpu().double() - ref).abs().max()) / scale
+    bal = float(err.sum() / err.abs().sum())
+    print(f"wgrad |dy|~{mag:g}: max-rel fp16x2 {e_h:.3e} bf16x3 {e_3:.3e} fp32 {e_32:.3e} sign balance {bal:+.3f}")
+    assert e_h <= 1.5 * e_32 + 1e-7
+    assert abs(bal) < 0.05, bal
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s", [
     (4, 24, 40, 64, 64, 3, 1), (2, 33, 29, 128, 128, 3, 1), (4, 16, 24, 64, 128, 3, 2), (2, 20, 36, 256, 128, 1, 1),
     (8, 12, 16, 512, 512, 3, 1), (2, 19, 21, 128, 80, 3, 1),

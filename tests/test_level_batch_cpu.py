@@ -32,7 +32,7 @@ def _gather(tag):
 def _wgrad(tag):
     g = DcsConvGeom()
     g.N = tag
-    return ("dcs_conv_wgrad_x3", C.c_void_p(tag), C.c_void_p(1), C.c_void_p(2), g, 64, 0, 2, None, C.c_void_p(0))
+    return ("dcs_conv_wgrad_x3", C.c_void_p(tag), C.c_void_p(1), C.c_void_p(2), g, 64, 0, 2, None, None, C.c_void_p(0))
 
 
 def _flat(calls):
