@@ -293,6 +293,25 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
   }
 }
 
+// max |x| of a tensor as the bit pattern of a float (see dcs_bn_bwd_apply's dy_maxabs): one filtered atomicMax per block
+__global__ __launch_bounds__(256)
+void maxabs_kernel(const float* __restrict__ x, const long long n4, unsigned* __restrict__ out, const int nt) {
+  float mx = 0.f;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    const float4 v = ld4s(x + i * 4, nt);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+  }
+  __shared__ float s_mx[4];
+  mx = dcs_wave_max(mx);
+  if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+    const unsigned bits = __float_as_uint(mx);
+    if (bits > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, bits);
+  }
+}
+
 __global__ void scale_inplace_kernel(float* __restrict__ x, long long n, const float* __restrict__ a,
                                      const float* __restrict__ b) {
   const float s = a[0] * (b ? b[0] : 1.f);
@@ -470,6 +489,13 @@ extern "C" int dcs_bn_bwd_apply(const float* g, const float* y, const float* mas
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
                        sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training, dy_maxabs);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_maxabs(const float* x, int64_t n, uint32_t* out, void* stream) {
+  DCS_CHECK_ARG(x && out && n > 0 && (n & 3) == 0 && dcs_aligned16(x));
+  hipLaunchKernelGGL(maxabs_kernel, dim3(grid_for(n / 4)), dim3(256), 0, dcs_stream(stream), x, (long long)(n / 4), out,
+                     dcs_streams((long long)n * 4) ? 1 : 0);
   DCS_LAUNCH_RET();
 }
 

@@ -82,6 +82,21 @@ __global__ void split_weight_kernel(const float* __restrict__ w, uint2* __restri
   o[0] = p1; o[4] = p2; o[8] = p3;
 }
 
+// the fp16 two-piece form: out [rows][wstride / 16][2][16] fp16 of w * 2^X2H_KW (64 B per 16-channel chunk)
+__global__ void split_weight_h2_kernel(const float* __restrict__ w, uint2* __restrict__ out, const long long n4,
+                                       const int wstride) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;      // float4 index
+  if (i >= n4) return;
+  const int s4 = wstride >> 2;
+  const long long row = i / s4;
+  const int k4 = (int)(i - row * s4);
+  const int c = k4 >> 2, q = k4 & 3;
+  uint2 p1, p2;
+  split2h_quad(ld4(w + i * 4), (float)(1 << X2H_KW), p1, p2);
+  uint2* o = out + ((row * (wstride >> 4) + c) * 2) * 4 + q;
+  o[0] = p1; o[4] = p2;
+}
+
 // Block coordinates of a kernel body: the hardware block id for single launches, the level-relative id inside a multi
 // launch (see the *_multi_kernel wrappers at the end of the kernels).
 struct BlkId { int x, nx, y; };
@@ -91,19 +106,27 @@ constexpr int X3_ROWB = 112;      // bytes per LDS row
 // STEM: the 7x7 / stride 2 stem on the NHWC4 image in its 14-tap form (ops.geom_stem_fwd): a tap is a filter half-row of
 // 4 pixels x 4 channels = 16 contiguous floats = exactly one chunk; lane quad q of a row is pixel q of the tap and is
 // range-checked on its own (network/backbone/resnet_pyramid.py:110-112).
-template <int BN, int BM = 128, bool STEM = false>
+// NP = 2: the fp16 two-piece form (split2h_quad; weights from dcs_split_weight_h2: 64-byte chunk images): LDS rows of 80 B,
+// three MFMAs per product; src scaled by 2^X2H_KX or, with src_max, by the power of two that puts the tensor's maximum into
+// [2^13, 2^14); the result by the inverse of both scales.
+template <int BN, int BM = 128, bool STEM = false, int NP = 3>
 __device__ __forceinline__
 void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
                            const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom& g,
                            const int accumulate, const int ntiles, float* __restrict__ stats, const int cps,
-                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro, const BlkId bi) {
+                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro, const BlkId bi,
+                           const unsigned* __restrict__ src_max = nullptr) {
+  constexpr int ROWB = NP == 3 ? X3_ROWB : 80;                     // LDS row
+  constexpr int WB = 32 * NP;                                       // bytes of one 16-channel chunk image of a weight row
+  constexpr int WU = 2 * NP;                                        // ... in 16-byte units
   // 128 x 128 and 128 x 64 tiles: waves 2 x 2; 256 x 64 (64-channel layers of large maps): waves 4 x 1, so that a wave
   // still owns a 64 x 64 sub-tile (24 MFMAs per chunk against 5-6 staging slots instead of 12 against 4)
   constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int A_BYTES = BM * X3_ROWB, B_BYTES = BN * X3_ROWB;
-  constexpr int SMEM_FLOATS = 2 * (A_BYTES + B_BYTES) / 4;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  constexpr int EPI_FLOATS_ = 4 * 32 * (TN * 32 + 4) + WM * BN * 2;                 // what conv_epilogue stages
+  constexpr int SMEM_FLOATS = 2 * (A_BYTES + B_BYTES) / 4 > EPI_FLOATS_ ? 2 * (A_BYTES + B_BYTES) / 4 : EPI_FLOATS_;
   constexpr int NA = BM / 64;                // A slots per thread: 64 rows x 4 float4 each
-  constexpr int NB = (BN * 6 + 255) / 256;   // B slots per thread: 16-byte pieces of the 96-byte row images
+  constexpr int NB = (BN * WU + 255) / 256;  // B slots per thread: 16-byte pieces of the row images
   constexpr int NSLOT = NA + NB;
   static_assert((BN == 128 || BN == 64) && (BM == 128 || (BM == 256 && BN == 64)) && TM == 2, "unsupported tile");
 
@@ -121,6 +144,15 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
   const bool has_pro = !STEM && pro != nullptr;
   if (has_pro)
     for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
+  float x2h_in = (float)(1 << X2H_KX), x2h_out = 1.f / (float)(1 << (X2H_KX + X2H_KW));
+  if (NP == 2 && src_max != nullptr) {
+    const unsigned mbits = __builtin_amdgcn_readfirstlane(*src_max);
+    const int e = (int)((mbits >> 23) & 0xffu) - 126;               // max = f 2^e, f in [0.5, 1)
+    int k = (mbits >> 23) == 0u ? 0 : 14 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    x2h_in = __uint_as_float((unsigned)(127 + k) << 23);
+    x2h_out = __uint_as_float((unsigned)(127 - k - X2H_KW) << 23);
+  }
 
   const int bid = dcs_xcd_remap(bi.x, bi.nx);
   const int ntile = bid % ntiles, mtile = bid / ntiles;
@@ -145,11 +177,11 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
   const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
   const int wchunks = g.wstride >> 4;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
-  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wsp), (long long)g.Cout * wchunks * 96);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wsp), (long long)g.Cout * wchunks * WB);
 
   if (tid < g.ntaps) {
     s_oy[tid] = g.offy[tid]; s_ox[tid] = g.offx[tid];
-    s_wo[tid] = (g.wofs[tid] >> 4) * 96;                       // byte offset of the tap's first chunk in a weight row
+    s_wo[tid] = (g.wofs[tid] >> 4) * WB;                       // byte offset of the tap's first chunk in a weight row
     s_to[tid] = (g.offy[tid] * g.SW + g.offx[tid]) * g.src_cstride;
   }
 
@@ -170,10 +202,10 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int e = tid + 256 * j;
-    const int brow = e / 6, bs = e - brow * 6;
-    const bool ok = e < BN * 6 && co0 + brow < g.Cout;
-    b_off[j] = ok ? ((co0 + brow) * wchunks) * 96 + bs * 16 : -1;
-    b_lds[j] = e < BN * 6 ? brow * X3_ROWB + bs * 16 : -1;
+    const int brow = e / WU, bs = e - brow * WU;
+    const bool ok = e < BN * WU && co0 + brow < g.Cout;
+    b_off[j] = ok ? ((co0 + brow) * wchunks) * WB + bs * 16 : -1;
+    b_lds[j] = e < BN * WU ? brow * ROWB + bs * 16 : -1;
   }
   __syncthreads();
 
@@ -193,7 +225,7 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
   int c_oy = 0, c_ox = 0, c_wo = 0, c_to = 0, c_kc = 0;
   auto next_chunk = [&]() {          // chunk parameters of ld_ch into c_*, then advance (stays on the last chunk)
     c_oy = s_oy[ld_t]; c_ox = s_ox[ld_t]; c_to = s_to[ld_t];
-    c_wo = s_wo[ld_t] + (ld_c0 >> 4) * 96;
+    c_wo = s_wo[ld_t] + (ld_c0 >> 4) * WB;
     c_kc = ld_c0 + lcol4 * 4;
     if (ld_ch + 1 < cend) {
       ld_ch += 1; ld_c0 += 16;
@@ -218,15 +250,22 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
       float4 v = rs[sl];
       if (has_pro) v = pro_apply(v, p_sc, p_sh, lim[sl]);
       if (decltype(NEG)::value) { v.x = -v.x; v.y = -v.y; v.z = -v.z; v.w = -v.w; }   // odd chunks: see the main loop
-      uint2 p1, p2, p3;
-      split3_quad(v, p1, p2, p3);
-      unsigned char* q = sm + buf * A_BYTES + (lrow + 64 * sl) * X3_ROWB + lcol4 * 8;
-      *reinterpret_cast<uint2*>(q) = p1;
-      *reinterpret_cast<uint2*>(q + 32) = p2;
-      *reinterpret_cast<uint2*>(q + 64) = p3;
+      unsigned char* q = sm + buf * A_BYTES + (lrow + 64 * sl) * ROWB + lcol4 * 8;
+      if constexpr (NP == 3) {
+        uint2 p1, p2, p3;
+        split3_quad(v, p1, p2, p3);
+        *reinterpret_cast<uint2*>(q) = p1;
+        *reinterpret_cast<uint2*>(q + 32) = p2;
+        *reinterpret_cast<uint2*>(q + 64) = p3;
+      } else {
+        uint2 p1, p2;
+        split2h_quad(v, x2h_in, p1, p2);
+        *reinterpret_cast<uint2*>(q) = p1;
+        *reinterpret_cast<uint2*>(q + 32) = p2;
+      }
     } else {
       const int j = sl - NA;
-      if (NB * 256 == BN * 6 || b_lds[j] >= 0)
+      if (NB * 256 == BN * WU || b_lds[j] >= 0)
         *reinterpret_cast<u32x4*>(sm + 2 * A_BYTES + buf * B_BYTES + b_lds[j]) = rb[j];
     }
   };
@@ -266,10 +305,12 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
   __syncthreads();
 
   // piece products, smallest first: (a1 b3), (a3 b1), (a2 b2), (a1 b2), (a2 b1), (a1 b1)
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-  constexpr int G = 6 * TM * TN;               // MFMAs per chunk
+  constexpr int NTERM = NP == 3 ? 6 : 3;
+  constexpr int PA[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};
+  constexpr int PB[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int G = NTERM * TM * TN;           // MFMAs per chunk
   constexpr int G0 = TM * TN;                  // issued before the staging starts
-  bf16x8 fa[TM][3], fb[TN][3];
+  bf16x8 fa[TM][NP], fb[TN][NP];
   // iteration i (parity PAR) computes chunk cbeg + i from LDS buffer PAR into acc[PAR], writes chunk cbeg + i + 1 (in
   // the registers; negated when i + 1 is odd) to the other buffer and re-loads the registers with chunk cbeg + i + 2
   auto step = [&](auto PAR) {
@@ -279,18 +320,22 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
       for (int q = 0; q < G; ++q) {
         if (q < lo || q >= hi) continue;
         const int term = q / (TM * TN), a = (q / TN) % TM, b = q % TN;
-        acc[par][a][b] =
-            __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[b][PB[term]], acc[par][a][b], 0, 0, 0);
+        if constexpr (NP == 3)
+          acc[par][a][b] =
+              __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[b][PB[term]], acc[par][a][b], 0, 0, 0);
+        else
+          acc[par][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a][PA[term]]),
+                                                                  __builtin_bit_cast(f16x8, fb[b][PB[term]]), acc[par][a][b], 0, 0, 0);
       }
     };
-    const unsigned char* Ab = sm + par * A_BYTES + (wm * TM * 32 + l31) * X3_ROWB + h * 16;
-    const unsigned char* Bb = sm + 2 * A_BYTES + par * B_BYTES + (wn * TN * 32 + l31) * X3_ROWB + h * 16;
+    const unsigned char* Ab = sm + par * A_BYTES + (wm * TM * 32 + l31) * ROWB + h * 16;
+    const unsigned char* Bb = sm + 2 * A_BYTES + par * B_BYTES + (wn * TN * 32 + l31) * ROWB + h * 16;
 #pragma unroll
-    for (int p = 2; p >= 0; --p) {
+    for (int p = NP - 1; p >= 0; --p) {
 #pragma unroll
-      for (int a = 0; a < TM; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + a * 32 * X3_ROWB + p * 32);
+      for (int a = 0; a < TM; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + a * 32 * ROWB + p * 32);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * X3_ROWB + p * 32);
+      for (int b = 0; b < TN; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * ROWB + p * 32);
     }
     mfma_range(0, G0);
     if (has_pro) load_pro(kc_held);
@@ -314,7 +359,10 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[0][a][b][r] -= acc[1][a][b][r];
+      for (int r = 0; r < 16; ++r) {
+        acc[0][a][b][r] -= acc[1][a][b][r];
+        if constexpr (NP == 2) acc[0][a][b][r] *= x2h_out;             // a power of two: exact
+      }
 
   conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
                                                  mtile, M, wm, wn, bnb, m0 + BM <= M);
@@ -1587,23 +1635,25 @@ __device__ __forceinline__ int multi_level(const MP& P) {
 
 #define DCS_BLK BlkId{(int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y}
 
-template <int BN, int BM = 128, bool STEM = false>
+template <int BN, int BM = 128, bool STEM = false, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
                            const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom g,
                            const int accumulate, const int ntiles, float* __restrict__ stats, const int cps,
-                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro) {
-  conv_gather_x3_body<BN, BM, STEM>(src, wsp, bias, dst, g, accumulate, ntiles, stats, cps, slab_stride, bnb, pro, DCS_BLK);
+                           const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro,
+                           const unsigned* __restrict__ src_max) {
+  conv_gather_x3_body<BN, BM, STEM, NP>(src, wsp, bias, dst, g, accumulate, ntiles, stats, cps, slab_stride, bnb, pro, DCS_BLK,
+                                        src_max);
 }
-template <int BN, int BM = 128, bool STEM = false>
+template <int BN, int BM = 128, bool STEM = false, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_x3_multi_kernel(const GatherMulti P) {
   const int lv = multi_level(P);
   const GatherSub& s = P.s[lv];
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
-  conv_gather_x3_body<BN, BM, STEM>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.cps, s.slab_stride,
-                                    s.bnb, s.pro, BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
+  conv_gather_x3_body<BN, BM, STEM, NP>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.cps, s.slab_stride,
+                                        s.bnb, s.pro, BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.src_max);
 }
 
 template <int BN, int TH, int NP = 3>
@@ -1698,10 +1748,20 @@ extern "C" int dcs_split_weight(const float* w, void* out, int64_t rows, int wst
   DCS_LAUNCH_RET();
 }
 
+extern "C" int dcs_split_weight_h2(const float* w, void* out, int64_t rows, int wstride, void* stream) {
+  DCS_CHECK_ARG(w && out && rows > 0 && wstride > 0 && (wstride & 15) == 0 && dcs_aligned16(w) && dcs_aligned16(out));
+  const long long n4 = (long long)rows * wstride / 4;
+  DCS_CHECK_ARG(n4 < (1ll << 31) * 256);
+  hipLaunchKernelGGL(split_weight_h2_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, dcs_stream(stream), w,
+                     reinterpret_cast<uint2*>(out), n4, wstride);
+  DCS_LAUNCH_RET();
+}
+
 namespace {
 
 // ---- launch plans: validation + kernel choice of one (sub-)launch, shared by the single and the multi entries -----------
-enum GatherKid { GK_X3W_64, GK_X3W_128, GK_X2H_64, GK_X2H_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64 };
+enum GatherKid { GK_X3W_64, GK_X3W_128, GK_X2H_64, GK_X2H_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64,
+                 GK_H2 = 32 /* flag: the per-tap kernels in their fp16 two-piece form */ };
 struct GatherPlan { int kid; DcsConvGeom g; GatherSub s; unsigned nbx, nby; };
 
 int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
@@ -1728,12 +1788,14 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
       return DCS_E_UNSUPPORTED;
   }
   const BnBwdEpi bnb{a.bn_y, a.bn_mask, a.bn, a.relu};
-  DCS_CHECK_ARG(!(a.stats && a.accumulate && !bnb.y));
+  const bool accum = (a.accumulate & 1) != 0, h2 = (a.accumulate & DCS_ACC_FP16X2) != 0;
+  DCS_CHECK_ARG((a.accumulate & ~(1 | DCS_ACC_FP16X2)) == 0);
+  DCS_CHECK_ARG(!(a.stats && accum && !bnb.y));
   DCS_CHECK_ARG(!a.pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(a.pro)));
   DCS_CHECK_ARG(!bnb.y || (a.stats && bnb.bn && nsplit == 1 && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
                            dcs_aligned16(a.dst) && dcs_aligned16(bnb.y) && (!bnb.mask || dcs_aligned16(bnb.mask))));
   if (nsplit > 1)
-    DCS_CHECK_ARG(!a.bias && !a.stats && !a.accumulate && a.slab_stride >= M * geom->dst_cstride);
+    DCS_CHECK_ARG(!a.bias && !a.stats && !accum && a.slab_stride >= M * geom->dst_cstride);
   const int bn_ = geom->Cout > 64 ? 128 : 64;
   const int ntiles = (geom->Cout + bn_ - 1) / bn_;
   // 64-wide layers of large maps: 256-pixel tiles (enough of them to fill the chip several times over)
@@ -1746,12 +1808,12 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
   if (nsplit > 1) cps += cps & 1;
   P.g = *geom;
   P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), a.bias, a.dst, a.stats, a.pro, bnb,
-                  (long long)a.slab_stride, (a.accumulate ? 1 : 0) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), ntiles, cps,
-                  0, 0u, 0, 0, 0};
+                  (long long)a.slab_stride, (accum ? 1 : 0) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), ntiles, cps,
+                  0, 0u, 0, 0, 0, h2 ? a.src_max : nullptr};
   P.nbx = (unsigned)blocks;
   P.nby = (unsigned)nsplit;
   // DCS_X3_HALO=0: never; =2: whenever the geometry allows (tests: small shapes); default: when there are enough tiles
-  const bool g_halo = dcs_config().x3_halo != 0;
+  const bool g_halo = dcs_config().x3_halo != 0 && !h2;              // (the LDS-weights halo kernel has no fp16 form)
   const bool g_halo_force = dcs_config().x3_halo == 2;
   if (g_halo && nsplit == 1 && (long long)geom->SH * geom->SW * geom->src_cstride * 4 <= 0x7FFFFFFFll) {
     // enough tiles to fill the chip twice over, else the per-tap kernel (and its K splits) does better
@@ -1768,6 +1830,7 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
   else if (bn_ == 128) P.kid = GK_128;
   else P.kid = bm256 ? GK_64_256 : GK_64;
   if (P.kid != GK_128 && P.kid != GK_64) DCS_CHECK_ARG(nsplit == 1);
+  if (h2) P.kid |= GK_H2;
   return DCS_OK;
 }
 
@@ -1831,25 +1894,21 @@ int launch_gather_one(const GatherPlan& P, hipStream_t s) {
     case GK_HALO_128:
       hipLaunchKernelGGL((conv3x3_x3_kernel<128, 4>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro);
       break;
-    case GK_STEM_256:
-      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256, true>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride,
-                         P.s.bnb, P.s.pro);
-      break;
-    case GK_STEM_128:
-      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 128, true>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride,
-                         P.s.bnb, P.s.pro);
-      break;
-    case GK_128:
-      hipLaunchKernelGGL(conv_gather_x3_kernel<128>, grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride, P.s.bnb,
-                         P.s.pro);
-      break;
-    case GK_64_256:
-      hipLaunchKernelGGL((conv_gather_x3_kernel<64, 256>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride,
-                         P.s.bnb, P.s.pro);
-      break;
-    default:
-      hipLaunchKernelGGL(conv_gather_x3_kernel<64>, grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps, P.s.slab_stride, P.s.bnb,
-                         P.s.pro);
+#define DCS_TAP(BN_, BM_, ST_)                                                                                                  \
+  do {                                                                                                                        \
+    if (P.kid & GK_H2)                                                                                                        \
+      hipLaunchKernelGGL((conv_gather_x3_kernel<BN_, BM_, ST_, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps,             \
+                         P.s.slab_stride, P.s.bnb, P.s.pro, P.s.src_max);                                                    \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((conv_gather_x3_kernel<BN_, BM_, ST_, 3>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps,             \
+                         P.s.slab_stride, P.s.bnb, P.s.pro, nullptr);                                                        \
+  } while (0)
+    case GK_STEM_256: case GK_STEM_256 | GK_H2: DCS_TAP(64, 256, true); break;
+    case GK_STEM_128: case GK_STEM_128 | GK_H2: DCS_TAP(64, 128, true); break;
+    case GK_128: case GK_128 | GK_H2: DCS_TAP(128, 128, false); break;
+    case GK_64_256: case GK_64_256 | GK_H2: DCS_TAP(64, 256, false); break;
+    default: DCS_TAP(64, 128, false);
+#undef DCS_TAP
   }
   return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;
 }
@@ -1892,6 +1951,11 @@ int launch_gather_multi(const GatherPlan* const* plans, int n, hipStream_t s) {
     case GK_128: hipLaunchKernelGGL(conv_gather_x3_multi_kernel<128>, grid, blk, 0, s, mp); break;
     case GK_64_256: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256>), grid, blk, 0, s, mp); break;
     case GK_64: hipLaunchKernelGGL(conv_gather_x3_multi_kernel<64>, grid, blk, 0, s, mp); break;
+    case GK_STEM_256 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, true, 2>), grid, blk, 0, s, mp); break;
+    case GK_STEM_128 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, true, 2>), grid, blk, 0, s, mp); break;
+    case GK_128 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<128, 128, false, 2>), grid, blk, 0, s, mp); break;
+    case GK_64_256 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, false, 2>), grid, blk, 0, s, mp); break;
+    case GK_64 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, false, 2>), grid, blk, 0, s, mp); break;
     default: return DCS_E_ARG;
   }
   return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;
@@ -2031,8 +2095,8 @@ int launch_wgrad_plans(const WgradPlan* plans, int n, hipStream_t s) {
 extern "C" int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, float* dst,
                                   const DcsConvGeom* geom, int accumulate, float* stats, const float* pro,
                                   const float* bn_y, const float* bn_mask, const float* bn, int relu, int nsplit,
-                                  int64_t slab_stride, void* stream) {
-  const DcsGatherLaunch a{src, wsplit, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, slab_stride, accumulate, relu, nsplit, nullptr};
+                                  int64_t slab_stride, const uint32_t* src_max, void* stream) {
+  const DcsGatherLaunch a{src, wsplit, bias, dst, geom, stats, pro, bn_y, bn_mask, bn, slab_stride, accumulate, relu, nsplit, src_max};
   GatherPlan P;
   const int rc = plan_gather_x3(a, P);
   return rc != DCS_OK ? rc : launch_gather_one(P, dcs_stream(stream));

@@ -56,7 +56,8 @@ SIGNATURES = {
     "dcs_conv_gather_split": [_P, _P, _P, C.POINTER(DcsConvGeom), _I, _L, _P],
     "dcs_conv_wgrad": [_P, _P, _P, _G, _I, _I, _I, _P],
     "dcs_split_weight": [_P, _P, _L, _I, _P],
-    "dcs_conv_gather_x3": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P],
+    "dcs_conv_gather_x3": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _I, _L, _P, _P],
+    "dcs_split_weight_h2": [_P, _P, _L, _I, _P],
     "dcs_split_weight_frag": [_P, _P, _L, _I, _P],
     "dcs_split_weight_frag_h2": [_P, _P, _L, _I, _P],
     "dcs_conv3x3_x3w": [_P, _P, _P, _P, _G, _I, _P, _P, _P, _P, _P, _I, _P, _P],
@@ -74,6 +75,7 @@ SIGNATURES = {
     "dcs_colsum_final": [_P, _P, _I, _I, _I, _F, _D, _P],
     "dcs_bn_finalize": [_P, _P, _P, _P, _P, _P, _I, _D, _F, _F, _I, _I, _P],
     "dcs_bn_ema_again": [_P, _P, _P, _I, _D, _F, _F, _P],
+    "dcs_maxabs": [_P, _L, _P, _P],
     "dcs_bn_act": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
     "dcs_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P],
     "dcs_normalize_pyramid": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],

@@ -435,6 +435,7 @@ class SwiftNetEngine:
         while pos >= 0 and tape[pos][0] == "blend":
             _, i, in_hw, t, bn, z, blend = tape[pos]
             pos -= 1
+            ops.tag_max(g_x)        # no BatchNorm backward produced this gradient: one pass for its maximum (fp16 two-piece kernels)
             wgrad(blend.conv, z, g_x, 1, 1, pro_of(z, t, bn))
             g_z, bs = ops.conv_dgrad(g_x, wp(blend.conv), t.shape[1:3], 1, 1, bnb=(t, None, bn, True))
             g_t, _ = bn_bwd(blend.norm, g_z, t, bn, relu=True, sums=bs)

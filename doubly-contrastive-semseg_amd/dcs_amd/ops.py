@@ -88,9 +88,8 @@ def _gather_struct(a, x3w):
     if x3w:      # dcs_conv3x3_x3w(src, wfrag, bias, dst, geom, accumulate, stats, pro, bn_y, bn_mask, bn, relu, src_max, stream)
         src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, smax, _ = a
         ns, slab = 1, 0
-    else:        # dcs_conv_gather_x3(..., relu, nsplit, slab_stride, stream)
-        src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, ns, slab, _ = a
-        smax = None
+    else:        # dcs_conv_gather_x3(..., relu, nsplit, slab_stride, src_max, stream)
+        src, w, bias, dst, g, acc, stats, pro, yb, mb, bnr, relu, ns, slab, smax, _ = a
     return _lib.DcsGatherLaunch(_ptr(src), _ptr(w), _ptr(bias), _ptr(dst), C.pointer(g), _ptr(stats), _ptr(pro), _ptr(yb),
                                 _ptr(mb), _ptr(bnr), slab, acc, relu, ns, _ptr(smax))
 
@@ -401,6 +400,18 @@ def _max_slot(device):
     return s
 
 
+def tag_max(t):
+    """Attach the device word with max |t| to a gradient tensor that no bn_bwd produced (one read of the tensor), so that
+    the 3x3 convolutions consuming it -- data and weight gradient -- take the fp16 two-piece kernels.  The caller
+    guarantees that t is not written again before they ran.  No-op on the CPU / with DCS_X2H=0 / when already tagged."""
+    if t is None or not t.is_cuda or not x2h_on() or hasattr(t, "_dcs_max") or t.numel() % 4 or not t.is_contiguous():
+        return t
+    slot = _max_slot(t.device)
+    _call("dcs_maxabs", _p(t), t.numel(), _p(slot), _stream())
+    t._dcs_max = slot
+    return t
+
+
 def new_step():
     """Weights may change between steps (optimizer): forget the split images of the previous step.  Called at the start of
     every model forward; within one forward + backward a weight (or its data-gradient repack) is split once and reused
@@ -445,6 +456,22 @@ def split_weight_frag(wk):
 
 
 ACC_FP16X2 = 16          # DCS_ACC_FP16X2 (include/dcs_hip.h)
+
+
+def split_weight_h2(wk):
+    """The fp16 two-piece form of split_weight (4 B / element), cached per step."""
+    key = ("h2", wk.data_ptr(), tuple(wk.shape), tuple(wk.stride()))
+    hit = _split_cache.get(key)
+    if hit is not None:
+        return hit[1]
+    rows = wk.shape[0]
+    ws = wk.numel() // rows
+    out = torch.empty((rows * ws,), device=wk.device, dtype=_F32)
+    _call_now("dcs_split_weight_h2", _p(wk), _p(out), rows, ws, _stream())
+    if len(_split_cache) >= 1024:
+        _split_cache.clear()
+    _split_cache[key] = (wk, out)
+    return out
 
 
 def split_weight_frag_h2(wk):
@@ -502,8 +529,13 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
             _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
                   _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, None, _stream())
     elif x3_ok(g):
-        _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
-              _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _stream())
+        smax = None if fwd else getattr(src, "_dcs_max", None)
+        if (fwd or smax is not None) and x2h_on():
+            _call("dcs_conv_gather_x3", _p(src), _p(split_weight_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
+                  _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _p(smax), _stream())
+        else:
+            _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
+                  _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, None, _stream())
     elif bnb is not None:
         assert pro is None and ns == 1
         _call("dcs_conv_gather_bnbwd", _p(src), _p(wgt), _p(dst), C.byref(g), accumulate, _p(yb), _p(mb), _p(bnr),
@@ -728,10 +760,10 @@ def stem_conv(p, wp, want_stats=False):
     g = geom_stem_fwd(N, H, W) if os.environ.get("DCS_STEM14", "1") != "0" else geom_stem(N, H, W)
     y = torch.empty((N, g.DH, g.DW, 64), device=p.device, dtype=_F32)
     if not want_stats:
-        _gather_launch(p, wp, None, y, g, 0, None)
+        _gather_launch(p, wp, None, y, g, 0, None, fwd=True)
         return y
     part, G, G1 = _stats_buffer(N * g.DH * g.DW, 64, p.device)
-    _gather_launch(p, wp, None, y, g, 0, part)
+    _gather_launch(p, wp, None, y, g, 0, part, fwd=True)
     return y, _stats_reduce(part, G, G1, 64, N * g.DH * g.DW)
 
 

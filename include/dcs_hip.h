@@ -121,9 +121,12 @@ int dcs_conv_wgrad_pro(const float* src, const float* dy, float* slab, const Dcs
  * =2: whenever the geometry allows).  wsplit = dcs_split_weight of the fp32 weight the fp32
  * entry would take.  Non-finite inputs give NaN (inf - inf in the split), not inf. */
 int dcs_split_weight(const float* w, void* out, int64_t rows, int wstride, void* stream);
+/* accumulate | DCS_ACC_FP16X2 (defined below): the fp16 two-piece form, as for dcs_conv3x3_x3w -- wsplit from
+ * dcs_split_weight_h2 ([rows][wstride/16][2][16] fp16 of w * 2^10), src_max as there (nullable: src scaled by 2^2). */
+int dcs_split_weight_h2(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, float* dst, const DcsConvGeom* geom,
                        int accumulate, float* stats, const float* pro, const float* bn_y, const float* bn_mask,
-                       const float* bn, int relu, int nsplit, int64_t slab_stride, void* stream);
+                       const float* bn, int relu, int nsplit, int64_t slab_stride, const uint32_t* src_max, void* stream);
 
 /* Dense 3x3 / stride 1 / pad 1 geometries (TX % 32 == 0, TY % 8 (Cout <= 64) or % 4 == 0, K % 32 == 0), weights straight
  * from global memory into the MFMA fragments: dcs_split_weight_frag lays them out fragment-major (unit
@@ -159,7 +162,7 @@ typedef struct DcsGatherLaunch {
   float* stats; const float* pro; const float* bn_y; const float* bn_mask; const float* bn;
   int64_t slab_stride;
   int32_t accumulate, relu, nsplit;
-  const uint32_t* src_max;   /* dcs_conv3x3_x3w with DCS_ACC_FP16X2 only (else null): see there */
+  const uint32_t* src_max;   /* with DCS_ACC_FP16X2 only (else null): see dcs_conv3x3_x3w */
 } DcsGatherLaunch;
 int dcs_conv_gather_x3_multi(const DcsGatherLaunch* launches, int n, void* stream);   /* n x dcs_conv_gather_x3 */
 int dcs_conv3x3_x3w_multi(const DcsGatherLaunch* launches, int n, void* stream);      /* n x dcs_conv3x3_x3w (nsplit 1) */
@@ -232,6 +235,9 @@ int dcs_bn_act(const float* y, const float* bn, const float* r, const float* bn2
  * dy_maxabs (nullable): device word, zero before the call; receives the bit pattern of max |dy| over the written tensor
  * (integer atomicMax of non-negative floats: order-independent, deterministic) -- the per-tensor scale of the fp16
  * two-piece convolution kernels that consume dy (dcs_conv3x3_x3w src_max, dcs_conv_wgrad_x3 dy_max). */
+/* out (zero before the call) receives the bit pattern of max |x| over n floats (n % 4 == 0), like dy_maxabs below: the
+ * per-tensor scale of the fp16 two-piece convolution kernels for a gradient that no BatchNorm backward produced. */
+int dcs_maxabs(const float* x, int64_t n, uint32_t* out, void* stream);
 int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
                      const float* gamma, const float* sums, float* dy, float* gm_out,
                      float* dgamma, float* dbeta, int64_t rows, int C, int relu, int acc_dy,

@@ -865,6 +865,7 @@ def test_split_bf16_convolution_with_resident_halo(ops, monkeypatch, libopt, N, 
     (bitwise equal to the materialised activation), data gradient accumulating into a tensor with the BatchNorm-backward
     sums; deterministic; fp32-class error without bias."""
     monkeypatch.setenv("DCS_KSPLIT", "0")                 # the halo kernel has no K splits
+    monkeypatch.setenv("DCS_X2H", "0")                    # the three-piece bf16 kernels are compared here
     x = rnd(N, H, W, Cin, seed=121)
     w = cl(rnd(Cout, Cin, 3, 3, seed=122, scale=0.05))
     ref = E.conv_fwd(x.double(), w.double(), 1, 1)
@@ -902,6 +903,7 @@ def test_halo_kernel_with_weight_fragments_from_global_memory(ops, monkeypatch, 
     import ctypes as C
     from dcs_amd.ops import _p, _call, _stream
     monkeypatch.setenv("DCS_KSPLIT", "0")
+    monkeypatch.setenv("DCS_X2H", "0")                    # the three-piece bf16 kernels are compared here
     libopt("x3_halo", 2)
     x = rnd(N, H, W, Cin, seed=131).to(DEV)
     w = cl(rnd(Cout, Cin, 3, 3, seed=132, scale=0.05).to(DEV))

@@ -26,7 +26,7 @@ def _gather(tag):
     g = DcsConvGeom()
     g.N = tag
     return ("dcs_conv_gather_x3", C.c_void_p(tag), C.c_void_p(1), None, C.c_void_p(2), g, 0, None, None, None, None, None, 0, 1, 0,
-            C.c_void_p(0))
+            None, C.c_void_p(0))
 
 
 def _wgrad(tag):
