@@ -142,7 +142,7 @@ class DeepLabEngine:
     def forward(self, img, training, supcon, need_grad, lazy_seg=False):
         bb, hd = self.bb, self.head
         self._nbt = []
-        ops.new_step()                 # split-weight images of the previous step are stale (optimizer)
+        ops.new_step(training)         # split-weight images of the previous step are stale (optimizer)
         tape = [] if need_grad else None
         parts = list(img) if isinstance(img, (list, tuple)) else [img]
         parts = [t if t.is_floating_point() else t.float() for t in parts]

@@ -242,7 +242,7 @@ class SwiftNetEngine:
         self._mean = fe.img_mean.reshape(3).contiguous()
         self._std = fe.img_std.reshape(3).contiguous()
         self._nbt = []
-        ops.new_step()                 # split-weight images of the previous step are stale (optimizer)
+        ops.new_step(training)         # split-weight images of the previous step are stale (optimizer)
         tape: List[tuple] = [] if need_grad else None
         parts = list(img) if isinstance(img, (list, tuple)) else [img]
         parts = [t if t.is_floating_point() else t.float() for t in parts]

@@ -412,14 +412,6 @@ def tag_max(t):
     return t
 
 
-def new_step():
-    """Weights may change between steps (optimizer): forget the split images of the previous step.  Called at the start of
-    every model forward; within one forward + backward a weight (or its data-gradient repack) is split once and reused
-    by the three pyramid levels."""
-    _split_cache.clear()
-    _max_pool["buf"] = None
-
-
 def split_weight(wk):
     """[rows, ...] fp32 (row length % 16 == 0) -> the three-piece bf16 image dcs_conv_gather_x3 stages (6 B / element).
     Cached per step by storage address; the cache entry keeps ``wk`` alive, so the address cannot be recycled."""
@@ -492,8 +484,25 @@ def split_weight_frag_h2(wk):
 
 
 def x2h_on():
-    """Forward 3x3 convolutions on two fp16 pieces (DCS_X2H=0: three bf16 pieces like the data gradients)."""
+    """Convolutions on two fp16 pieces per operand where they apply (DCS_X2H=0: three bf16 pieces everywhere)."""
     return os.environ.get("DCS_X2H", "1") != "0"
+
+
+# Forward convolutions take the fp16 two-piece kernels only while the activations are known to be of order one: in
+# TRAINING mode every convolution input is a batch-normalised tensor (or a short sum of them, or the normalised image), far
+# inside the kernels' domain |x| < 16384.  An eval-mode forward normalises with running statistics that need not match the
+# data (a freshly initialised ResNet-101 lets its activations grow through 33 residual blocks): it keeps the three-piece
+# bf16 kernels, whose range is fp32's.  Gradients are always scaled by their measured maximum.
+_x2h_forward = [True]
+
+
+def new_step(training=True):
+    """Start of a model forward.  Weights may change between steps (optimizer): forget the split images of the previous
+    step; within one forward + backward a weight (or its data-gradient repack) is split once and reused by the three
+    pyramid levels.  training: batch-statistics BatchNorm -> forward convolutions may use the fp16 two-piece kernels."""
+    _split_cache.clear()
+    _max_pool["buf"] = None
+    _x2h_forward[0] = bool(training)
 
 
 def x3w_ok(g):
@@ -522,7 +531,7 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
     if ns == 1 and x3_ok(g) and x3w_ok(g):
         smax = None if fwd else getattr(src, "_dcs_max", None)
-        if (fwd or smax is not None) and x2h_on():
+        if ((fwd and _x2h_forward[0]) or smax is not None) and x2h_on():
             _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
                   _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _p(smax), _stream())
         else:
@@ -530,7 +539,7 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
                   _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, None, _stream())
     elif x3_ok(g):
         smax = None if fwd else getattr(src, "_dcs_max", None)
-        if (fwd or smax is not None) and x2h_on():
+        if ((fwd and _x2h_forward[0]) or smax is not None) and x2h_on():
             _call("dcs_conv_gather_x3", _p(src), _p(split_weight_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
                   _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _p(smax), _stream())
         else:
@@ -717,7 +726,8 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
     if x3:
         slab = torch.empty((ns, n), device=x.device, dtype=_F32)
         # dy out of bn_bwd carries the device word with its maximum: the rolling 3x3 kernel then runs on two fp16 pieces
-        dmax = getattr(dy, "_dcs_max", None) if x2h_on() else None
+        # (the input operand is an activation: only after a training-mode forward, see _x2h_forward)
+        dmax = getattr(dy, "_dcs_max", None) if (x2h_on() and _x2h_forward[0]) else None
         _call("dcs_conv_wgrad_x3", _p(x), _p(dy), _p(slab), g, dy.shape[3], 0, ns, _p(pro), _p(dmax), _stream())
     else:
         if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 32 == 0:

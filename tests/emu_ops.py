@@ -34,7 +34,7 @@ def krsc(w):
 PRO_MAXK = 512
 
 
-def new_step():
+def new_step(training=True):
     pass
 
 

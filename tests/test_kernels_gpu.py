@@ -711,6 +711,7 @@ def test_fp16_two_piece_forward_convolution_has_fp32_class_error(ops, monkeypatc
     statistics epilogue; small and large magnitudes inside the documented domain."""
     monkeypatch.setenv("DCS_KSPLIT", "0")
     monkeypatch.setenv("DCS_X3W_MIN", "1")                 # the weight-fragment kernel on these small maps
+    ops.new_step(True)                                      # as a training-mode forward does (an eval forward keeps bf16)
     x = rnd(N, H, W, Cin, seed=141)
     x[0, :2] *= 300.0                                       # large activations
     x[-1, -2:] *= 1e-3                                      # and tiny ones
@@ -789,6 +790,7 @@ def test_fp16_two_piece_weight_gradient(ops, monkeypatch, N, H, W, Cin, Cout, ma
     """Weight gradients of 3x3 / stride 1 convolutions on two fp16 pieces (rolling-window kernel; dy out of bn_bwd with its
     maximum word, the input with the BatchNorm + ReLU prologue): error vs a float64 weight gradient <= 1.5x the exact-fp32
     kernels', no rounding bias, deterministic, another kernel than the bf16 one."""
+    ops.new_step(True)                                      # the input operand is a training-mode activation
     g = rnd(N, H, W, Cout, seed=161) * mag
     g.view(-1)[::997] *= 1000.0
     yb = rnd(N, H, W, Cout, seed=162)
