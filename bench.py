@@ -14,9 +14,9 @@ Weak scaling: every rank keeps B=16.
 roofline: dominant kernel family = the implicit-GEMM gather launches (conv forward + data gradient; every launch: plain,
 split-K, fused prologue / epilogue, level-batched).  achieved = algorithmic fp32 FLOPs (2*M*taps*K*Cout per launch,
 SURVEY.md 8(d)) / summed launch time measured with HIP events recorded on the launch stream during the timed steps.
-peak = 416.7 TFLOP/s fp32-equivalent when most of those FLOPs ran on the split-bf16 kernels (dense bf16 MFMA peak 2500 / 6
-piece products per fp32 product, MI355X_MICROARCH.md), else the 157.3 TFLOP/s of the fp32 MFMA; the fraction of the fp32
-MFMA peak is reported next to it.  roofline.hbm_family: the HBM-bound rest of the step (BatchNorm, pooling, resizes, fused
+peak = the speed of light of the arithmetic the launches used: dense 16-bit MFMA peak 2500 TFLOP/s (MI355X_MICROARCH.md) / 3
+piece products (two fp16 pieces per operand) = 833.3, / 6 (three bf16 pieces) = 416.7, or the 157.3 of the fp32 MFMA,
+weighted by algorithmic FLOPs; the fraction of the fp32 MFMA peak is reported next to it.  roofline.hbm_family: the HBM-bound rest of the step (BatchNorm, pooling, resizes, fused
 seg loss ...) as algorithmic bytes / HIP-event time against 8 TB/s, measured in two extra steps after the timed region.
 cpu_baseline: the oracle (pure-PyTorch CPU restatement, kind "port") on a bounded sample of the same workload.
 """
@@ -39,6 +39,11 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 # the speed of light of that scheme in fp32-equivalent (algorithmic) FLOP/s is the dense bf16 MFMA peak / 6
 PEAK_BF16_MFMA_TFLOPS = 2500.0
 PEAK_X3_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+# fp32 convolutions on the fp16 matrix cores (round 3): two fp16 pieces per operand, three piece products per fp32 product;
+# the dense fp16 MFMA peak equals the bf16 one (MI355X_MICROARCH.md)
+PEAK_X2H_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 3.0
+ACC_FP16X2 = 16
+SCHEME_PEAK = {"fp32": PEAK_FP32_MFMA_TFLOPS, "bf16x3": PEAK_X3_TFLOPS, "fp16x2": PEAK_X2H_TFLOPS}
 
 
 def parse():
@@ -104,9 +109,21 @@ class ConvProfiler:
             if self.enabled and base in self.GEOM_ARG:
                 if name in self.MULTI:
                     geoms = [args[0][i].geom.contents for i in range(args[1])]
+                    if base == "dcs_conv_wgrad_x3":
+                        h2 = [bool(args[0][i].dy_max) and self._roll_ok(args[0][i].geom.contents) for i in range(args[1])]
+                    else:
+                        h2 = [bool(args[0][i].accumulate & ACC_FP16X2) for i in range(args[1])]
                 else:
                     ga = args[self.GEOM_ARG[name]]
                     geoms = [getattr(ga, "_obj", ga)]
+                    if base == "dcs_conv_wgrad_x3":
+                        h2 = [args[8] is not None and self._roll_ok(geoms[0])]
+                    elif base in ("dcs_conv_gather_x3", "dcs_conv3x3_x3w"):
+                        h2 = [bool(args[5] & ACC_FP16X2)]
+                    else:
+                        h2 = [False]
+                x3 = base.endswith(("_x3", "_x3w"))
+                schemes = [("fp16x2" if hh else "bf16x3") if x3 else "fp32" for hh in h2]
                 flops = sum(cost(g)[0] for g in geoms)
                 abytes = sum(cost(g)[1] for g in geoms)
                 g = geoms[0]
@@ -124,10 +141,19 @@ class ConvProfiler:
                     fused += "*%d" % len(geoms)
                 key = (kind + ("+" + fused if fused else ""), g.N, g.SH, g.SW, g.TY, g.TX, g.K, g.Cout, g.ntaps, g.sy, g.dsy,
                        g.stem)
-                self.records.append((kind, flops, e0, e1, key, abytes, base.endswith(("_x3", "_x3w"))))
+                by_scheme = {}
+                for gg, sc in zip(geoms, schemes):
+                    by_scheme[sc] = by_scheme.get(sc, 0.0) + cost(gg)[0]
+                self.records.append((kind, flops, e0, e1, key + (max(by_scheme, key=by_scheme.get),), abytes, by_scheme))
             else:
                 self._orig(name, *args)
         ops._call_now = wrapped
+
+    @staticmethod
+    def _roll_ok(g):
+        """The geometries dcs_conv_wgrad_x3 runs on its rolling-window kernel (the only one with an fp16 two-piece form)."""
+        return (not g.stem and g.ntaps == 9 and g.sy == 1 and g.dsy == 1 and g.sx == 1 and g.TX % 16 == 0 and g.SH == g.TY and g.SW == g.TX and
+                g.wstride == 9 * g.K and all(g.offy[t] == t // 3 - 1 and g.offx[t] == t % 3 - 1 for t in range(9)))
 
     def per_shape(self):
         agg = {}
@@ -137,7 +163,7 @@ class ConvProfiler:
         rows = []
         for key, (n, ms, fl) in agg.items():
             rows.append(dict(kernel=key[0], N=key[1], SH=key[2], SW=key[3], TY=key[4], TX=key[5], K=key[6], Cout=key[7],
-                             taps=key[8], sy=key[9], dsy=key[10], stem=key[11], launches=n, ms=ms,
+                             taps=key[8], sy=key[9], dsy=key[10], stem=key[11], scheme=key[12], launches=n, ms=ms,
                              tflops=fl / (ms * 1e-3) / 1e12))
         rows.sort(key=lambda r: -r["ms"])
         return rows
@@ -150,8 +176,14 @@ class ConvProfiler:
                 continue
             ms = sum(r[2].elapsed_time(r[3]) for r in rs)
             fl = sum(r[1] for r in rs)
-            x3 = sum(r[1] for r in rs if r[6])
-            out[name] = dict(launches=len(rs), ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12, x3_flop_share=x3 / max(fl, 1.0),
+            share = {}
+            for r in rs:
+                for sc, f in r[6].items():
+                    share[sc] = share.get(sc, 0.0) + f
+            share = {k: v / max(fl, 1.0) for k, v in share.items()}
+            # speed of light of the mix: total FLOPs / sum of (FLOPs of a scheme / that scheme's peak)
+            peak = 1.0 / sum(v / SCHEME_PEAK[k] for k, v in share.items()) if share else PEAK_FP32_MFMA_TFLOPS
+            out[name] = dict(launches=len(rs), ms=ms, flops=fl, tflops=fl / (ms * 1e-3) / 1e12, scheme_flop_share=share, peak=peak,
                              avg_us=ms * 1e3 / len(rs), alg_bytes_per_launch=sum(r[5] for r in rs) / len(rs),
                              alg_flops_per_launch=fl / len(rs))
         return out
@@ -159,30 +191,32 @@ class ConvProfiler:
 
 def roofline(g, wg, args, world):
     """The dominant kernel family: the implicit-GEMM gather launches (conv forward + data gradient), all of them -- plain,
-    split-K, with fused prologue / epilogue, fp32-MFMA and split-bf16 -- timed live with HIP events.  `achieved` counts
-    ALGORITHMIC fp32 FLOPs (2 M K Cout per launch).  When most of them ran on the split-bf16 kernels the peak is the dense
-    bf16 MFMA peak / 6 (six piece products per fp32 product: 2500 / 6 = 416.7 TFLOP/s), else the fp32 MFMA peak."""
-    def peak_of(s):
-        return PEAK_X3_TFLOPS if s.get("x3_flop_share", 0.0) > 0.5 else PEAK_FP32_MFMA_TFLOPS
-    pk, pkw = peak_of(g), peak_of(wg)
+    split-K, with fused prologue / epilogue, level-batched -- timed live with HIP events.  `achieved` counts ALGORITHMIC
+    fp32 FLOPs (2 M K Cout per launch).  `peak` is the speed of light of the arithmetic actually used: a launch runs its
+    fp32 products as three fp16 piece products (dense fp16 MFMA peak 2500 / 3 = 833.3 TFLOP/s fp32-equivalent), six bf16
+    ones (2500 / 6 = 416.7) or on the fp32 MFMA (157.3); the family's peak is total FLOPs / sum(FLOPs_i / peak_i)."""
+    pk, pkw = g.get("peak", PEAK_FP32_MFMA_TFLOPS), wg.get("peak", PEAK_FP32_MFMA_TFLOPS)
     return {"bound": "mfma", "achieved": g["tflops"], "peak": pk, "unit": "TFLOP/s", "frac": g["tflops"] / pk,
-            "peak_note": ("fp32-equivalent peak of the split-bf16 scheme = dense bf16 MFMA peak 2500 / 6 piece products"
-                          if pk == PEAK_X3_TFLOPS else "dense fp32 MFMA peak"),
+            "peak_note": "fp32-equivalent speed of light of the launch mix: dense 16-bit MFMA peak 2500 TFLOP/s / 3 (two fp16 "
+                         "pieces per operand) or / 6 (three bf16 pieces), fp32 MFMA 157.3; weighted by algorithmic FLOPs",
             "frac_of_fp32_mfma_peak": g["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-            "split_bf16_flop_share": g.get("x3_flop_share", 0.0),
-            "traffic": pmc_traffic(args, world),
+            "scheme_flop_share": g.get("scheme_flop_share", {}),
+            "traffic": pmc_traffic(args, world, "conv_gather"),
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md)",
             "algorithmic_bytes_per_launch": g.get("alg_bytes_per_launch"),
             "algorithmic_flops_per_launch": g.get("alg_flops_per_launch"),
-            "kernel": "conv3x3_x3w[_multi]_kernel / conv_gather_x3[_multi]_kernel / conv_gather_kernel (conv forward + data gradient, the pyramid levels of a layer in one launch; fp32 operands as three "
-                      "bf16 pieces on v_mfma_f32_32x32x16_bf16, the rest exact fp32 on v_mfma_f32_32x32x2_f32)",
+            "kernel": "conv3x3_x3w[_multi]_kernel / conv_gather_x3[_multi]_kernel / conv_gather_kernel (conv forward + data gradient, "
+                      "the pyramid levels of a layer in one launch; fp32 operands as two fp16 pieces on v_mfma_f32_32x32x16_f16 or "
+                      "three bf16 pieces on v_mfma_f32_32x32x16_bf16, the rest exact fp32 on v_mfma_f32_32x32x2_f32)",
             "launches_per_step": g["launches"] // max(args.steps, 1), "avg_launch_us": g["avg_us"],
             "ms_per_step": g["ms"] / max(args.steps, 1),
             "wgrad_kernel": {"achieved": wg["tflops"], "peak": pkw, "frac": wg["tflops"] / pkw,
                              "frac_of_fp32_mfma_peak": wg["tflops"] / PEAK_FP32_MFMA_TFLOPS,
-                             "split_bf16_flop_share": wg.get("x3_flop_share", 0.0),
+                             "scheme_flop_share": wg.get("scheme_flop_share", {}),
                              "ms_per_step": wg["ms"] / max(args.steps, 1),
-                             "launches_per_step": wg["launches"] // max(args.steps, 1)}}
+                             "launches_per_step": wg["launches"] // max(args.steps, 1),
+                             "algorithmic_bytes_per_launch": wg.get("alg_bytes_per_launch"),
+                             "traffic": pmc_traffic(args, world, "conv_wgrad")}}
 
 
 def cpu_baseline(O, args):
@@ -209,16 +243,16 @@ def cpu_baseline(O, args):
                       f"{args.width}x{args.height}, {args.criterion}, oracle/swiftnet_oracle.py on torch CPU"}
 
 
-def pmc_traffic(args, world):
-    """HBM bytes per conv_gather launch from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
+def pmc_traffic(args, world, family="conv_gather"):
+    """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r02_l_pmc_traffic_c3.json")
+    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_c3.json")
     default = (args.batch, args.height, args.width, args.criterion, args.model) == \
         (16, 1024, 2048, "supcon_pixelcontrast_focal", "resnet18")
     if not (default and os.path.exists(path)):
         return None
     with open(path) as f:
-        return json.load(f)["conv_gather"]["hbm_bytes_per_launch"]
+        return json.load(f).get(family, {}).get("hbm_bytes_per_launch")
 
 
 def hbm_family_pass(ops, one_step, steps=2):
