@@ -110,14 +110,14 @@ class ConvProfiler:
                 if name in self.MULTI:
                     geoms = [args[0][i].geom.contents for i in range(args[1])]
                     if base == "dcs_conv_wgrad_x3":
-                        h2 = [bool(args[0][i].dy_max) and self._roll_ok(args[0][i].geom.contents) for i in range(args[1])]
+                        h2 = [bool(args[0][i].dy_max) for i in range(args[1])]
                     else:
                         h2 = [bool(args[0][i].accumulate & ACC_FP16X2) for i in range(args[1])]
                 else:
                     ga = args[self.GEOM_ARG[name]]
                     geoms = [getattr(ga, "_obj", ga)]
                     if base == "dcs_conv_wgrad_x3":
-                        h2 = [args[8] is not None and self._roll_ok(geoms[0])]
+                        h2 = [args[8] is not None]      # every split weight-gradient kernel has the fp16 form
                     elif base in ("dcs_conv_gather_x3", "dcs_conv3x3_x3w"):
                         h2 = [bool(args[5] & ACC_FP16X2)]
                     else:
@@ -148,12 +148,6 @@ class ConvProfiler:
             else:
                 self._orig(name, *args)
         ops._call_now = wrapped
-
-    @staticmethod
-    def _roll_ok(g):
-        """The geometries dcs_conv_wgrad_x3 runs on its rolling-window kernel (the only one with an fp16 two-piece form)."""
-        return (not g.stem and g.ntaps == 9 and g.sy == 1 and g.dsy == 1 and g.sx == 1 and g.TX % 16 == 0 and g.SH == g.TY and g.SW == g.TX and
-                g.wstride == 9 * g.K and all(g.offy[t] == t // 3 - 1 and g.offx[t] == t % 3 - 1 for t in range(9)))
 
     def per_shape(self):
         agg = {}

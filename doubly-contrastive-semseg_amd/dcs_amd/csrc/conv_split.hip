@@ -384,15 +384,17 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int BT>
+// NP = 2 (dy_max given): the fp16 two-piece form, scaled like conv_wgrad3x3_x3r_body<2> (input by 2^X2H_KX, dy by its maximum).
+template <int BT, int NP = 3>
 __device__ __forceinline__
 void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                           const DcsConvGeom& g, const int dy_cstride, const int split0, const long long mps,
-                          const int ciT, const float* __restrict__ pro, const BlkId bi) {
+                          const int ciT, const float* __restrict__ pro, const BlkId bi,
+                          const unsigned* __restrict__ dy_max = nullptr) {
   constexpr int T = BT / 64;             // 32x32 tiles per wave per dim
   constexpr int CHP = 16;                // pixels per chunk
   constexpr int PIECE = BT * 2;          // bytes of one piece of one pixel row
-  constexpr int ROW = 3 * PIECE + 64;    // 832 (BT = 128) / 448 (BT = 64)
+  constexpr int ROW = NP * PIECE + 64;   // 832 / 448 (NP = 3: BT = 128 / 64), 576 / 320 (NP = 2): all = 64 or 192 (mod 256)
   constexpr int Q = BT / 4;              // channel quads per operand tile
   constexpr int NI = CHP * Q / 256;      // float4 per thread per operand and chunk: 2 / 1
   constexpr int NSLOT = 2 * NI;
@@ -405,6 +407,15 @@ void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wid >> 1, wn = wid & 1;
   const int sq = tid % Q, spx = tid / Q;     // staging: channel quad, first pixel (items: pixel spx + (256 / Q) * i)
+  float sc_dy = 1.f, sc_out = 1.f;
+  if (NP == 2) {
+    const unsigned mbits = __builtin_amdgcn_readfirstlane(*dy_max);
+    const int e = (int)((mbits >> 23) & 0xffu) - 126;               // max = f 2^e, f in [0.5, 1)
+    int k = (mbits >> 23) == 0u ? 0 : 14 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    sc_dy = __uint_as_float((unsigned)(127 + k) << 23);
+    sc_out = __uint_as_float((unsigned)(127 - k - X2H_KX) << 23);
+  }
 
   const int bx = bi.x;
   const int t = bx % g.ntaps;
@@ -467,12 +478,19 @@ void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
     } else if (has_pro) {
       v = pro_apply(v, p_sc, p_sh, lim[i]);
     }
-    uint2 p1, p2, p3;
-    split3_quad(v, p1, p2, p3);
     unsigned char* q = sm + (sl < NI ? 0 : 2 * OPB) + buf * OPB + (spx + (256 / Q) * i) * ROW + sq * 8;
-    *reinterpret_cast<uint2*>(q) = p1;
-    *reinterpret_cast<uint2*>(q + PIECE) = p2;
-    *reinterpret_cast<uint2*>(q + 2 * PIECE) = p3;
+    if constexpr (NP == 3) {
+      uint2 p1, p2, p3;
+      split3_quad(v, p1, p2, p3);
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + PIECE) = p2;
+      *reinterpret_cast<uint2*>(q + 2 * PIECE) = p3;
+    } else {
+      uint2 p1, p2;
+      split2h_quad(v, sl < NI ? sc_dy : (float)(1 << X2H_KX), p1, p2);
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + PIECE) = p2;
+    }
   };
 
   f32x16 acc[T][T];
@@ -497,9 +515,11 @@ void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
   // group parity selects channels 0-15 / 16-31 of the 32-channel tile, lane half h the pixels 8h .. 8h+7 (two reads)
   const int tj = lane & 15;
   const int tr_off = (8 * h + (tj >> 2)) * ROW + (16 * ((lane >> 4) & 1) + 4 * (tj & 3)) * 2;
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PB[6] = {2, 0, 1, 1, 0, 0};
-  constexpr int G = 6 * T * T, G0 = T * T;
-  bf16x8 fa[T][3], fb[T][3];
+  constexpr int NTERM = NP == 3 ? 6 : 3;
+  constexpr int PA[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};       // smallest products first
+  constexpr int PB[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
+  constexpr int G = NTERM * T * T, G0 = T * T;
+  bf16x8 fa[T][NP], fb[T][NP];
   auto frag = [&](const unsigned char* base) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * ROW));
@@ -511,7 +531,11 @@ void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
     for (int q = 0; q < G; ++q) {
       if (q < lo || q >= hi) continue;
       const int term = q / (T * T), a = (q / T) % T, b = q % T;
-      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[b][PB[term]], acc[a][b], 0, 0, 0);
+      if constexpr (NP == 3)
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[b][PB[term]], acc[a][b], 0, 0, 0);
+      else
+        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a][PA[term]]),
+                                                           __builtin_bit_cast(f16x8, fb[b][PB[term]]), acc[a][b], 0, 0, 0);
     }
   };
   for (long long ch = 0; ch < nch; ++ch) {
@@ -519,7 +543,7 @@ void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
     const unsigned char* Db = sm + buf * OPB + tr_off + (wm * T * 32) * 2;
     const unsigned char* Xb = sm + 2 * OPB + buf * OPB + tr_off + (wn * T * 32) * 2;
 #pragma unroll
-    for (int p = 2; p >= 0; --p) {
+    for (int p = NP - 1; p >= 0; --p) {
 #pragma unroll
       for (int a = 0; a < T; ++a) fa[a][p] = frag(Db + p * PIECE + a * 64);
 #pragma unroll
@@ -547,7 +571,7 @@ void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + (wm * T + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (co < g.Cout) out[(long long)co * g.wstride + wo + ci] = odd ? -acc[a][b][r] : acc[a][b][r];
+        if (co < g.Cout) out[(long long)co * g.wstride + wo + ci] = (odd ? -acc[a][b][r] : acc[a][b][r]) * (NP == 2 ? sc_out : 1.f);
       }
     }
 }
@@ -958,19 +982,31 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
 // every lane of a 16-lane group supplies its own address, so the Toeplitz structure needs no im2col copy here either.
 // Wave w owns filter rows 2w, 2w+1 (row 7 does not exist) x both 32-channel output tiles.  Odd splits: (-dy), negated
 // output (rounding-bias cancellation, see conv_wgrad_x3_kernel).
+// NP = 2 (dy_max given): fp16 two-piece form -- the image by 2^X2H_KX, dy by its maximum (conv_wgrad3x3_x3r_body<2>).
+template <int NP = 3>
 __device__ __forceinline__
 void stem_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
-                          const DcsConvGeom& g, const int dy_cstride, const int split0, const int cps, const BlkId bi) {
+                          const DcsConvGeom& g, const int dy_cstride, const int split0, const int cps, const BlkId bi,
+                          const unsigned* __restrict__ dy_max = nullptr) {
   constexpr int CHP = 16, PWP = 38;                    // pixels per chunk, patch width in pixels
-  constexpr int PIECE = 128, ROW = 3 * PIECE + 64;     // dy image: 448-byte rows
+  constexpr int PIECE = 128, ROW = NP * PIECE + 64;    // dy image: 448- / 320-byte rows
   constexpr int PL = PWP * 8;                          // bytes of one (filter row, piece) run: 38 px x 4 ch x 2 B = 304
-  constexpr int DB = CHP * ROW, PB = 7 * 3 * PL;
+  constexpr int DB = CHP * ROW, PB = 7 * NP * PL;
   __shared__ __attribute__((aligned(16))) unsigned char sm[2 * DB + 2 * PB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wid = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int lcol4 = tid & 15, lrow = tid >> 4;
+  float sc_dy = 1.f, sc_out = 1.f;
+  if (NP == 2) {
+    const unsigned mbits = __builtin_amdgcn_readfirstlane(*dy_max);
+    const int e = (int)((mbits >> 23) & 0xffu) - 126;               // max = f 2^e, f in [0.5, 1)
+    int k = (mbits >> 23) == 0u ? 0 : 14 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    sc_dy = __uint_as_float((unsigned)(127 + k) << 23);
+    sc_out = __uint_as_float((unsigned)(127 - k - X2H_KX) << 23);
+  }
   const int split = bi.x;
   const bool odd = ((split0 + split) & 1) != 0;
   const int cpr = g.TX / CHP;
@@ -1034,14 +1070,21 @@ void stem_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
     } else {
       const int k = sl - 1;
       if (!ps_ok[k]) return;
-      q = sm + 2 * DB + buf * PB + ps_r[k] * 3 * PL + ps_c[k] * 8;
+      q = sm + 2 * DB + buf * PB + ps_r[k] * NP * PL + ps_c[k] * 8;
       pstride = PL;
     }
-    uint2 p1, p2, p3;
-    split3_quad(v, p1, p2, p3);
-    *reinterpret_cast<uint2*>(q) = p1;
-    *reinterpret_cast<uint2*>(q + pstride) = p2;
-    *reinterpret_cast<uint2*>(q + 2 * pstride) = p3;
+    if constexpr (NP == 3) {
+      uint2 p1, p2, p3;
+      split3_quad(v, p1, p2, p3);
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + pstride) = p2;
+      *reinterpret_cast<uint2*>(q + 2 * pstride) = p3;
+    } else {
+      uint2 p1, p2;
+      split2h_quad(v, sl == 0 ? sc_dy : (float)(1 << X2H_KX), p1, p2);
+      *reinterpret_cast<uint2*>(q) = p1;
+      *reinterpret_cast<uint2*>(q + pstride) = p2;
+    }
   };
 
   f32x16 acc[2][2];                         // [filter row 2w + a][output-channel tile]
@@ -1067,7 +1110,9 @@ void stem_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
   const int ccol = 16 * ((lane >> 4) & 1) + 4 * (tj & 3);            // first of its four columns
   const int d_off = prow * ROW + ccol * 2;
   const int p_off = (8 * prow + ccol) * 2;
-  constexpr int PA[6] = {0, 2, 1, 0, 1, 0}, PBt[6] = {2, 0, 1, 1, 0, 0};
+  constexpr int NTERM = NP == 3 ? 6 : 3;
+  constexpr int PA[6] = {NP == 3 ? 0 : 1, NP == 3 ? 2 : 0, NP == 3 ? 1 : 0, 0, 1, 0};       // smallest products first
+  constexpr int PBt[6] = {NP == 3 ? 2 : 0, NP == 3 ? 0 : 1, NP == 3 ? 1 : 0, 1, 0, 0};
   auto frag = [&](const unsigned char* base, int second) {
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + second));
@@ -1080,22 +1125,29 @@ void stem_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
     const int buf = ch & 1;
     const unsigned char* Db = sm + buf * DB + d_off;
     const unsigned char* Pb = sm + 2 * DB + buf * PB + p_off;
-    bf16x8 fa[2][3], fb[2][3];
+    bf16x8 fa[2][NP], fb[2][NP];
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < NP; ++p) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) fa[b][p] = frag(Db + p * PIECE + b * 64, 4 * ROW);
-      fb[0][p] = frag(Pb + (r0 * 3 + p) * PL, 64);                    // 4 pixels further = 4 x 16 bytes
-      fb[1][p] = frag(Pb + ((two ? r0 + 1 : r0) * 3 + p) * PL, 64);
+      fb[0][p] = frag(Pb + (r0 * NP + p) * PL, 64);                   // 4 pixels further = 4 x 16 bytes
+      fb[1][p] = frag(Pb + ((two ? r0 + 1 : r0) * NP + p) * PL, 64);
     }
 #pragma unroll
-    for (int term = 0; term < 6; ++term) {
+    for (int term = 0; term < NTERM; ++term) {
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
-        acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][PA[term]], fb[0][PBt[term]], acc[0][b], 0, 0, 0);
-        if (two) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][PA[term]], fb[1][PBt[term]], acc[1][b], 0, 0, 0);
+        if constexpr (NP == 3) {
+          acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][PA[term]], fb[0][PBt[term]], acc[0][b], 0, 0, 0);
+          if (two) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[b][PA[term]], fb[1][PBt[term]], acc[1][b], 0, 0, 0);
+        } else {
+          acc[0][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[b][PA[term]]),
+                                                             __builtin_bit_cast(f16x8, fb[0][PBt[term]]), acc[0][b], 0, 0, 0);
+          if (two) acc[1][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[b][PA[term]]),
+                                                                      __builtin_bit_cast(f16x8, fb[1][PBt[term]]), acc[1][b], 0, 0, 0);
+        }
       }
-      if (term < 3) {
+      if (term < 3) {                      // three staging slots behind the first three MFMA groups
         store_slot(term, buf ^ 1);
         load_slot(term);
         __builtin_amdgcn_sched_barrier(0);
@@ -1115,7 +1167,7 @@ void stem_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int co = b * 32 + (q & 3) + 8 * (q >> 2) + 4 * h;
-        out[(long long)co * g.wstride + r * 32 + l31] = odd ? -acc[a][b][q] : acc[a][b][q];
+        out[(long long)co * g.wstride + r * 32 + l31] = (odd ? -acc[a][b][q] : acc[a][b][q]) * (NP == 2 ? sc_out : 1.f);
       }
   }
 }
@@ -1337,6 +1389,12 @@ void conv3x3_x3_kernel(const float* __restrict__ src, const unsigned char* __res
 // NP = 3: three bf16 pieces, six products (above).  NP = 2: two fp16 pieces, three products (split2h_quad; the weight
 // fragments come from dcs_split_weight_frag in its fp16 form): same structure, LDS row = [piece 1: 16 fp16][piece 2][16 B
 // pad] = 80 B (5 x 16 B: conflict-free b128 reads), results scaled back by 2^-(X2H_KX + X2H_KW) before the epilogue.
+// DCS_X3W_EXP (compile time, tools/x3w_parts.sh; never set in the product build): timing experiments that switch parts of
+// the loop off (results discarded) -- 1: no halo replacement, 2: no weight loads, 4: no fragment reads, 8: no epilogue, 32: every weight load reads chunk 0 (L1 hits),
+// 16: ONE accumulator set, no rounding-bias cancellation (fp16 form only; results kept: for tools/conv_bias_probe.py).
+#ifndef DCS_X3W_EXP
+#define DCS_X3W_EXP 0
+#endif
 template <int BN, int TH, int NP = 3>
 __device__ __forceinline__
 void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
@@ -1450,12 +1508,12 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
   int lw_kc = 0, lw_t = 0;            // the next weight chunk to load
   auto load_w = [&](auto S) {         // chunk parity S: odd chunks come from the sign-flipped copy
     constexpr int s_ = decltype(S)::value;
-    const int c = s_wc[lw_t] + lw_kc;
+    const int c = (DCS_X3W_EXP & 32) ? 0 : s_wc[lw_t] + lw_kc;
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int p = 0; p < NP; ++p) {
-        const unsigned off = (unsigned)(((c * J + jt0 + b) * NP + p) * 1024) + lane16 + (s_ ? neg_off : 0u);
+        const unsigned off = (unsigned)(((c * J + jt0 + b) * NP + p) * 1024) + lane16 + ((s_ && !(DCS_X3W_EXP & 16)) ? neg_off : 0u);
         fb[s_][b][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
       }
     if (lw_kc * 9 + lw_t + 1 < nch) { lw_t += 1; if (lw_t == 9) { lw_t = 0; lw_kc += 1; } }
@@ -1488,12 +1546,18 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
   auto step = [&](auto PAR) {
     constexpr int par = decltype(PAR)::value;
     const unsigned char* Ab = Abase + s_ho[t];
+#if DCS_X3W_EXP & 4
+    if (kc == 0 && t == 0)
+#endif
 #pragma unroll
     for (int o = 0; o < NP; ++o) {
       const int pa = NP == 3 ? (o == 0 ? 0 : (o == 1 ? 2 : 1)) : (1 - o);
 #pragma unroll
       for (int a = 0; a < TM; ++a) fa[a][pa] = *reinterpret_cast<const bf16x8*>(Ab + a * HWD * ROWB + pa * 32);
     }
+#if DCS_X3W_EXP & 2
+    if (kc == 0 && t < 2)
+#endif
     load_w(std::integral_constant<int, 1 - par>{});                 // the next chunk's weight fragments
 #pragma unroll
     for (int term = 0; term < NTERM; ++term)
@@ -1505,19 +1569,21 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
             acc[par][a][b] =
                 __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][PA[term]], fb[par][b][PB[term]], acc[par][a][b], 0, 0, 0);
           else
-            acc[par][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a][PA[term]]),
-                                                                    __builtin_bit_cast(f16x8, fb[par][b][PB[term]]),
-                                                                    acc[par][a][b], 0, 0, 0);
+            acc[(DCS_X3W_EXP & 16) ? 0 : par][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                __builtin_bit_cast(f16x8, fa[a][PA[term]]), __builtin_bit_cast(f16x8, fb[par][b][PB[term]]),
+                acc[(DCS_X3W_EXP & 16) ? 0 : par][a][b], 0, 0, 0);
         }
     t += 1;
     if (t == 9) {
       t = 0; kc += 1;
+#if !(DCS_X3W_EXP & 1)
       if (kc < kch) {
         __syncthreads();
         store_halo(kc);
         if (kc + 1 < kch) load_halo(kc + 1);
         __syncthreads();
       }
+#endif
     }
   };
   for (int i = 0; i < nch; i += 2) {
@@ -1534,6 +1600,18 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
         if constexpr (NP == 2) acc[0][a][b][r] *= x2h_out;             // a power of two: exact
       }
   __syncthreads();                         // the halo is dead: the epilogue reuses its LDS
+#if DCS_X3W_EXP & 8
+  {
+    float sacc = 0.f;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc += acc[0][a][b][r];
+    if (sacc != 12345.678f) return;
+  }
+#endif
 
   conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
                                                  mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb, true);
@@ -1675,22 +1753,22 @@ void conv3x3_x3w_multi_kernel(const GatherMulti P) {
                                BlkId{rel, s.nbx, 0}, s.src_max);
 }
 
-template <int BT>
+template <int BT, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                           const DcsConvGeom g, const int dy_cstride, const int split0, const long long mps,
-                          const int ciT, const float* __restrict__ pro) {
-  conv_wgrad_x3_body<BT>(src, dy, slab, g, dy_cstride, split0, mps, ciT, pro, DCS_BLK);
+                          const int ciT, const float* __restrict__ pro, const unsigned* __restrict__ dy_max) {
+  conv_wgrad_x3_body<BT, NP>(src, dy, slab, g, dy_cstride, split0, mps, ciT, pro, DCS_BLK, dy_max);
 }
-template <int BT>
+template <int BT, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_x3_multi_kernel(const WgradMulti P) {
   const int lv = multi_level(P);
   const WgradSub& s = P.s[lv];
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
-  conv_wgrad_x3_body<BT>(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.mps, s.ciT, s.pro,
-                         BlkId{rel % s.nbx, s.nbx, rel / s.nbx});
+  conv_wgrad_x3_body<BT, NP>(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.mps, s.ciT, s.pro,
+                             BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.dy_max);
 }
 
 template <int NP = 3>
@@ -1711,18 +1789,21 @@ void conv_wgrad3x3_x3r_multi_kernel(const WgradMulti P) {
                              BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.dy_max);
 }
 
+template <int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void stem_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
-                          const DcsConvGeom g, const int dy_cstride, const int split0, const int cps) {
-  stem_wgrad_x3_body(src, dy, slab, g, dy_cstride, split0, cps, DCS_BLK);
+                          const DcsConvGeom g, const int dy_cstride, const int split0, const int cps,
+                          const unsigned* __restrict__ dy_max) {
+  stem_wgrad_x3_body<NP>(src, dy, slab, g, dy_cstride, split0, cps, DCS_BLK, dy_max);
 }
+template <int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void stem_wgrad_x3_multi_kernel(const WgradMulti P) {
   const int lv = multi_level(P);
   const WgradSub& s = P.s[lv];
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
-  stem_wgrad_x3_body(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.cps, BlkId{rel, s.nbx, 0});
+  stem_wgrad_x3_body<NP>(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.cps, BlkId{rel, s.nbx, 0}, s.dy_max);
 }
 
 // geometries conv3x3_x3_kernel covers: the nine taps of a dense 3x3 / stride 1 / pad 1 window in any order
@@ -1981,7 +2062,7 @@ int launch_gather_plans(const GatherPlan* plans, int n, hipStream_t s) {
   return DCS_OK;
 }
 
-enum WgradKid { WK_STEM, WK_ROLL, WK_ROLL_H2, WK_NINE, WK_128, WK_64 };
+enum WgradKid { WK_STEM, WK_ROLL, WK_ROLL_H2, WK_NINE, WK_128, WK_64, WK_128_H2, WK_64_H2, WK_STEM_H2 };
 struct WgradPlan { int kid; DcsConvGeom g; WgradSub s; unsigned nbx, nby; };
 
 int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
@@ -2002,7 +2083,7 @@ int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
     const int cps = (int)((nchunks + nsplit - 1) / nsplit);
     const long long span = ((long long)cps * 32 + 8ll * geom->SW) * 16;
     if ((long long)cps * 16 * dy_cstride * 4 >= 0x7FFFFFFFll || span >= 0x7FFFFFFFll) return DCS_E_UNSUPPORTED;
-    P.kid = WK_STEM; P.s.cps = cps; P.nbx = (unsigned)nsplit; P.nby = 1;
+    P.kid = a.dy_max ? WK_STEM_H2 : WK_STEM; P.s.dy_max = a.dy_max; P.s.cps = cps; P.nbx = (unsigned)nsplit; P.nby = 1;
     return DCS_OK;
   }
   if (geom->Cout & 3) return DCS_E_UNSUPPORTED;
@@ -2037,7 +2118,8 @@ int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
   }
   const int bt = (geom->Cout > 64 && geom->K > 64) ? 128 : 64;
   const int coT = (geom->Cout + bt - 1) / bt, ciT = (geom->K + bt - 1) / bt;
-  P.kid = bt == 128 ? WK_128 : WK_64;
+  P.kid = bt == 128 ? (a.dy_max ? WK_128_H2 : WK_128) : (a.dy_max ? WK_64_H2 : WK_64);      // dy_max: the fp16 two-piece form
+  P.s.dy_max = a.dy_max;
   P.s.mps = mps; P.s.ciT = ciT; P.s.cps = 0;
   P.nbx = (unsigned)(geom->ntaps * coT * ciT);
   return DCS_OK;
@@ -2047,12 +2129,15 @@ int plan_wgrad_x3(const DcsWgradLaunch& a, WgradPlan& P) {
 int launch_wgrad_one(const WgradPlan& P, hipStream_t s) {
   const dim3 grid(P.nbx, P.nby), blk(256);
   switch (P.kid) {
-    case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps); break;
+    case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_kernel<3>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, nullptr); break;
+    case WK_STEM_H2: hipLaunchKernelGGL(stem_wgrad_x3_kernel<2>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.dy_max); break;
     case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel<3>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro, nullptr); break;
     case WK_ROLL_H2: hipLaunchKernelGGL(conv_wgrad3x3_x3r_kernel<2>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro, P.s.dy_max); break;
     case WK_NINE: hipLaunchKernelGGL(conv_wgrad3x3_x3_kernel, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.cps, P.s.ciT, P.s.pro); break;
-    case WK_128: hipLaunchKernelGGL(conv_wgrad_x3_kernel<128>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro); break;
-    default: hipLaunchKernelGGL(conv_wgrad_x3_kernel<64>, grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro);
+    case WK_128: hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 3>), grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro, nullptr); break;
+    case WK_128_H2: hipLaunchKernelGGL((conv_wgrad_x3_kernel<128, 2>), grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro, P.s.dy_max); break;
+    case WK_64_H2: hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 2>), grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro, P.s.dy_max); break;
+    default: hipLaunchKernelGGL((conv_wgrad_x3_kernel<64, 3>), grid, blk, 0, s, DCS_WGRAD_ARGS(P), P.s.mps, P.s.ciT, P.s.pro, nullptr);
   }
   return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;
 }
@@ -2063,11 +2148,14 @@ int launch_wgrad_multi(const WgradPlan* const* plans, int n, hipStream_t s) {
   if (total <= 0 || total >= (1ll << 31)) return DCS_E_ARG;
   const dim3 grid((unsigned)total), blk(256);
   switch (plans[0]->kid) {
-    case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_multi_kernel, grid, blk, 0, s, mp); break;
+    case WK_STEM: hipLaunchKernelGGL(stem_wgrad_x3_multi_kernel<3>, grid, blk, 0, s, mp); break;
+    case WK_STEM_H2: hipLaunchKernelGGL(stem_wgrad_x3_multi_kernel<2>, grid, blk, 0, s, mp); break;
     case WK_ROLL: hipLaunchKernelGGL(conv_wgrad3x3_x3r_multi_kernel<3>, grid, blk, 0, s, mp); break;
     case WK_ROLL_H2: hipLaunchKernelGGL(conv_wgrad3x3_x3r_multi_kernel<2>, grid, blk, 0, s, mp); break;
-    case WK_128: hipLaunchKernelGGL(conv_wgrad_x3_multi_kernel<128>, grid, blk, 0, s, mp); break;
-    case WK_64: hipLaunchKernelGGL(conv_wgrad_x3_multi_kernel<64>, grid, blk, 0, s, mp); break;
+    case WK_128: hipLaunchKernelGGL((conv_wgrad_x3_multi_kernel<128, 3>), grid, blk, 0, s, mp); break;
+    case WK_64: hipLaunchKernelGGL((conv_wgrad_x3_multi_kernel<64, 3>), grid, blk, 0, s, mp); break;
+    case WK_128_H2: hipLaunchKernelGGL((conv_wgrad_x3_multi_kernel<128, 2>), grid, blk, 0, s, mp); break;
+    case WK_64_H2: hipLaunchKernelGGL((conv_wgrad_x3_multi_kernel<64, 2>), grid, blk, 0, s, mp); break;
     default: return DCS_E_ARG;
   }
   return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;

@@ -213,10 +213,12 @@ __global__ __launch_bounds__(256)
 void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, const float* __restrict__ y,
                               const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
                               float* __restrict__ dy, float* __restrict__ dgamma, float* __restrict__ dbeta, int N, int H,
-                              int W, int OH, int OW, int C, int acc_param, int training, int nt) {
+                              int W, int OH, int OW, int C, int acc_param, int training, int nt,
+                              unsigned* __restrict__ dy_maxabs) {
   const int C4 = C >> 2;
   const int QH = (H + 1) >> 1, QW = (W + 1) >> 1;
   const long long total = (long long)N * QH * QW * C4;
+  float mx = 0.f;
   const float inv = training ? (float)(1.0 / ((double)N * H * W)) : 0.f;
   if (blockIdx.x == 0 && dgamma) {
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
@@ -249,6 +251,18 @@ void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __rest
       o.z = gw.z * is.z * (v.z - s0.z * inv - (yy.z - mu.z) * is.z * (s1.z * inv));
       o.w = gw.w * is.w * (v.w - s0.w * inv - (yy.w - mu.w) * is.w * (s1.w * inv));
       st4s(dy + off, o, nt);
+      mx = fmaxf(fmaxf(mx, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
+    }
+  }
+  if (dy_maxabs) {                       // max |dy| as float bits, one filtered atomic per block (see bn_bwd_apply_kernel)
+    __shared__ float s_mx[4];
+    mx = dcs_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+      const unsigned bits = __float_as_uint(mx);
+      if (bits > __hip_atomic_load(dy_maxabs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(dy_maxabs, bits);
     }
   }
 }
@@ -574,14 +588,14 @@ extern "C" int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const
 
 extern "C" int dcs_bn_pool_bwd_apply(const float* g, const uint8_t* idx, const float* y, const float* bn, const float* gamma,
                                      const float* sums, float* dy, float* dgamma, float* dbeta, int N, int H, int W, int C,
-                                     int acc_param, int training, void* stream) {
+                                     int acc_param, int training, uint32_t* dy_maxabs, void* stream) {
   DCS_CHECK_ARG(g && idx && y && bn && gamma && sums && dy && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0);
   DCS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr));
   const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   const long long total = (long long)N * ((H + 1) / 2) * ((W + 1) / 2) * (C / 4);
   hipLaunchKernelGGL(bn_pool_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), g, idx, y, bn, gamma,
                      sums, dy, dgamma, dbeta, N, H, W, OH, OW, C, acc_param, training,
-                     dcs_streams((long long)N * H * W * C * 4) ? 1 : 0);
+                     dcs_streams((long long)N * H * W * C * 4) ? 1 : 0, dy_maxabs);
   DCS_LAUNCH_RET();
 }
 

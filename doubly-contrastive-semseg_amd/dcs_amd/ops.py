@@ -787,7 +787,8 @@ def stem_wgrad(p, dy, dwp, accumulate):
         ns = max(2, min(512, M // 64))
         ns += ns & 1
         slab = torch.empty((ns, 64 * 224), device=p.device, dtype=_F32)
-        _call("dcs_conv_wgrad_x3", _p(p), _p(dy), _p(slab), g, 64, 0, ns, None, None, _stream())
+        dmax = getattr(dy, "_dcs_max", None) if x2h_on() else None     # fp16 two-piece form (the image is bounded)
+        _call("dcs_conv_wgrad_x3", _p(p), _p(dy), _p(slab), g, 64, 0, ns, None, _p(dmax), _stream())
         _call("dcs_reduce_slab", _p(slab), _p(dwp), 64 * 224, ns, 1 if accumulate else 0, 0, 0, _stream())
         return
     ns = max(1, min(512, M // 64)) if g.DW % 32 == 0 else _nsplit(7, M)   # seven-row stem kernel: one block per split
@@ -956,8 +957,11 @@ def bn_pool_bwd(g, idx, y, bn, gamma, dgamma=None, dbeta=None, acc_param=False, 
     sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
     _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, 0.0, _stream())
     dy = torch.empty_like(y)
+    smax = _max_slot(y.device) if (y.is_cuda and x2h_on()) else None     # max |dy|: fp16 two-piece stem weight gradient
     _call("dcs_bn_pool_bwd_apply", _p(g), _p(idx), _p(y), _p(bn), _p(gamma), _p(sums), _p(dy), _p(dgamma), _p(dbeta),
-          N, H, W, Cc, 1 if acc_param else 0, 1 if training else 0, _stream())
+          N, H, W, Cc, 1 if acc_param else 0, 1 if training else 0, _p(smax), _stream())
+    if smax is not None:
+        dy._dcs_max = smax
     return dy
 
 

@@ -256,12 +256,14 @@ int dcs_maxpool_bwd(const float* g, const uint8_t* idx, float* gz, int N, int H,
 /* Backward of bn1 -> relu -> maxpool (resnet_pyramid.py:322-325) WITHOUT the dense pooled-gradient tensor: both passes
  * gather the gradient of a 2x2 pixel quad from its four pooling windows (g, idx at [N,OH,OW,C]) on the fly.
  * partial: [groups][2][C] (sum of masked gradient, sum of gradient * xhat) -> dcs_colsum_final -> sums [2][C];
- * apply: dy [N,H,W,C] = BatchNorm input gradient, dgamma/dbeta written or accumulated.  y = saved conv output. */
+ * apply: dy [N,H,W,C] = BatchNorm input gradient, dgamma/dbeta written or accumulated.  y = saved conv output.
+ * dy_maxabs (may be null): as in dcs_bn_bwd_apply -- the word is raised to the bits of max |dy| (the fp16 two-piece stem
+ * weight gradient scales dy by it). */
 int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const float* y, const float* bn, float* partial,
                             int N, int H, int W, int C, int groups, void* stream);
 int dcs_bn_pool_bwd_apply(const float* g, const uint8_t* idx, const float* y, const float* bn, const float* gamma,
                           const float* sums, float* dy, float* dgamma, float* dbeta, int N, int H, int W, int C,
-                          int acc_param, int training, void* stream);
+                          int acc_param, int training, uint32_t* dy_maxabs, void* stream);
 /* network/utils.py:92-102: t = bilinear(x -> [OH,OW], align_corners=False) + ((s0+s1)+s2). */
 int dcs_upsample_add(const float* x, const float* s0, const float* s1, const float* s2, float* t,
                      int N, int IH, int IW, int OH, int OW, int C, void* stream);

@@ -12,7 +12,7 @@ import dcs_amd.ops as ops
 dev = "cuda:0"
 torch.manual_seed(0)
 for positive in (True, False):
-    for (N, H, W, Cin, Cout) in [(2, 32, 48, 64, 64), (1, 24, 32, 512, 128)]:
+    for (N, H, W, Cin, Cout) in [(8, 64, 128, 64, 64), (4, 64, 128, 512, 128), (4, 64, 128, 2304, 128)]:
         x = torch.randn(N, H, W, Cin)
         w = (torch.randn(Cout, Cin, 3, 3) * 0.05)
         if positive:
