@@ -240,7 +240,9 @@ def cpu_baseline(O, args):
 def pmc_traffic(args, world, family="conv_gather"):
     """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
-    path = os.path.join(ROOT, "profiles", "r03_pmc_traffic_c3.json")
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_pmc_traffic_c3.json")))     # the latest set of the round
+    path = cands[-1] if cands else ""
     default = (args.batch, args.height, args.width, args.criterion, args.model) == \
         (16, 1024, 2048, "supcon_pixelcontrast_focal", "resnet18")
     if not (default and os.path.exists(path)):
