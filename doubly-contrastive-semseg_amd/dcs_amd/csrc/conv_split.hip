@@ -99,7 +99,17 @@ __global__ void split_weight_h2_kernel(const float* __restrict__ w, uint2* __res
 
 // Block coordinates of a kernel body: the hardware block id for single launches, the level-relative id inside a multi
 // launch (see the *_multi_kernel wrappers at the end of the kernels).
-struct BlkId { int x, nx, y; };
+struct BlkId { int x, nx, y, ny = 0; };      // ny > 0: the kernel may re-map (x, y) over the nx * ny grid (XCD locality)
+// Weight-gradient grids are (operand tiles) x (pixel splits): the blocks of ONE split read the same dy / input pixels.  Hardware
+// block ids go round-robin over the 8 XCDs, which would hand those blocks to 8 different L2s (each fetching the pixels from
+// the fabric again: PMC FETCH_SIZE 2.1x the algorithmic bytes); re-mapped, a split's tiles are neighbours on one XCD.
+__device__ __forceinline__ void wgrad_blk(const BlkId bi, int& bx, int& by) {
+  bx = bi.x; by = bi.y;
+  if (bi.ny > 0 && bi.nx > 1) {          // one tile per split: nothing shared, keep the interleaved order
+    const int l = dcs_xcd_remap(bi.y * bi.nx + bi.x, bi.nx * bi.ny);
+    bx = l % bi.nx; by = l / bi.nx;
+  }
+}
 
 constexpr int X3_ROWB = 112;      // bytes per LDS row
 
@@ -417,12 +427,12 @@ void conv_wgrad_x3_body(const float* __restrict__ src, const float* __restrict__
     sc_out = __uint_as_float((unsigned)(127 - k - X2H_KX) << 23);
   }
 
-  const int bx = bi.x;
+  int bx, split;
+  wgrad_blk(bi, bx, split);
   const int t = bx % g.ntaps;
   const int rest = bx / g.ntaps;
   const int ciTile = rest % ciT, coTile = rest / ciT;
   const int co0 = coTile * BT, ci0 = ciTile * BT;
-  const int split = bi.y;
   const bool odd = ((split0 + split) & 1) != 0;
 
   const long long TYX = (long long)g.TY * g.TX;
@@ -782,9 +792,10 @@ void conv_wgrad3x3_x3r_body(const float* __restrict__ src, const float* __restri
     sc_out = __uint_as_float((unsigned)(127 - k - X2H_KX) << 23);
   }
 
-  const int ciTile = bi.x % ciT, coTile = bi.x / ciT;
+  int bx, split;
+  wgrad_blk(bi, bx, split);
+  const int ciTile = bx % ciT, coTile = bx / ciT;
   const int co0 = coTile * 64, ci0 = ciTile * 64;
-  const int split = bi.y;
   const bool odd = ((split0 + split) & 1) != 0;
   const int cpr = g.TX / CHP;                           // strips per image
   const int nunits_total = g.N * cpr * g.TY;
@@ -1712,6 +1723,7 @@ __device__ __forceinline__ int multi_level(const MP& P) {
 }
 
 #define DCS_BLK BlkId{(int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y}
+#define DCS_BLK2 BlkId{(int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y}
 
 template <int BN, int BM = 128, bool STEM = false, int NP = 3>
 __global__ __launch_bounds__(256, 2)
@@ -1758,7 +1770,7 @@ __global__ __launch_bounds__(256, 2)
 void conv_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                           const DcsConvGeom g, const int dy_cstride, const int split0, const long long mps,
                           const int ciT, const float* __restrict__ pro, const unsigned* __restrict__ dy_max) {
-  conv_wgrad_x3_body<BT, NP>(src, dy, slab, g, dy_cstride, split0, mps, ciT, pro, DCS_BLK, dy_max);
+  conv_wgrad_x3_body<BT, NP>(src, dy, slab, g, dy_cstride, split0, mps, ciT, pro, DCS_BLK2, dy_max);
 }
 template <int BT, int NP = 3>
 __global__ __launch_bounds__(256, 2)
@@ -1768,7 +1780,7 @@ void conv_wgrad_x3_multi_kernel(const WgradMulti P) {
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
   conv_wgrad_x3_body<BT, NP>(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.mps, s.ciT, s.pro,
-                             BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.dy_max);
+                             BlkId{rel % s.nbx, s.nbx, rel / s.nbx, s.nblk / s.nbx}, s.dy_max);
 }
 
 template <int NP = 3>
@@ -1776,7 +1788,7 @@ __global__ __launch_bounds__(256, 2)
 void conv_wgrad3x3_x3r_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
                               const DcsConvGeom g, const int dy_cstride, const int split0, const int cps, const int ciT,
                               const float* __restrict__ pro, const unsigned* __restrict__ dy_max) {
-  conv_wgrad3x3_x3r_body<NP>(src, dy, slab, g, dy_cstride, split0, cps, ciT, pro, DCS_BLK, dy_max);
+  conv_wgrad3x3_x3r_body<NP>(src, dy, slab, g, dy_cstride, split0, cps, ciT, pro, DCS_BLK2, dy_max);
 }
 template <int NP = 3>
 __global__ __launch_bounds__(256, 2)
@@ -1786,7 +1798,7 @@ void conv_wgrad3x3_x3r_multi_kernel(const WgradMulti P) {
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
   conv_wgrad3x3_x3r_body<NP>(s.src, s.dy, s.slab, P.g[lv], s.dy_cstride, s.split0, s.cps, s.ciT, s.pro,
-                             BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.dy_max);
+                             BlkId{rel % s.nbx, s.nbx, rel / s.nbx, s.nblk / s.nbx}, s.dy_max);
 }
 
 template <int NP = 3>
