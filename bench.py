@@ -197,6 +197,8 @@ def roofline(g, wg, args, world):
             "scheme_flop_share": g.get("scheme_flop_share", {}),
             "traffic": pmc_traffic(args, world, "conv_gather"),
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md)",
+            "traffic_source": "committed PMC passes over this same command, not measured in this run: profiles/" +
+                              os.path.basename(pmc_traffic_file()),
             "algorithmic_bytes_per_launch": g.get("alg_bytes_per_launch"),
             "algorithmic_flops_per_launch": g.get("alg_flops_per_launch"),
             "kernel": "conv3x3_x3w[_multi]_kernel / conv_gather_x3[_multi]_kernel / conv_gather_kernel (conv forward + data gradient, "
@@ -237,12 +239,16 @@ def cpu_baseline(O, args):
                       f"{args.width}x{args.height}, {args.criterion}, oracle/swiftnet_oracle.py on torch CPU"}
 
 
+def pmc_traffic_file():
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_pmc_traffic_c3.json")))     # the latest set of the round
+    return cands[-1] if cands else ""
+
+
 def pmc_traffic(args, world, family="conv_gather"):
     """HBM bytes per launch of a kernel family from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE run
     separately on this same command, see profiles/README.md); None when the workload differs from the profiled one."""
-    import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r03_*_pmc_traffic_c3.json")))     # the latest set of the round
-    path = cands[-1] if cands else ""
+    path = pmc_traffic_file()
     default = (args.batch, args.height, args.width, args.criterion, args.model) == \
         (16, 1024, 2048, "supcon_pixelcontrast_focal", "resnet18")
     if not (default and os.path.exists(path)):
@@ -432,6 +438,11 @@ def main():
             "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "precision_note": "fp32 storage, accumulation and results (the reference's dtype); inside the convolution kernels an "
+                              "fp32 product is formed from two fp16 pieces per operand of an exactly (power-of-two) scaled value "
+                              "-- 22 significand bits, three MFMA products, h2*h2' <= 2^-22 |ab| dropped -- with errors against "
+                              "float64 at or below the exact-fp32 MFMA kernels' (tests/test_kernels_gpu.py::test_fp16_two_piece_*); "
+                              "DCS_X2H=0 / DCS_CONV_X3=0 select the bf16 three-piece / exact-fp32 MFMA kernels",
             "config": {"workload": (f"C5: DeepLabV3+ RN101 (OS16)" if deeplab else cfg_name + ": SwiftNet-RN18 pyramid") +
                                    f" + {args.criterion}, B={b}/GPU labelled images x {crops} crops "
                                    f"at {args.width}x{args.height}, fwd+losses+bwd+Adam",
