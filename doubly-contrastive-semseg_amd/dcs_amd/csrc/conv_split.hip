@@ -1402,6 +1402,7 @@ void conv3x3_x3_kernel(const float* __restrict__ src, const unsigned char* __res
 // pad] = 80 B (5 x 16 B: conflict-free b128 reads), results scaled back by 2^-(X2H_KX + X2H_KW) before the epilogue.
 // DCS_X3W_EXP (compile time, tools/x3w_parts.sh; never set in the product build): timing experiments that switch parts of
 // the loop off (results discarded) -- 1: no halo replacement, 2: no weight loads, 4: no fragment reads, 8: no epilogue, 32: every weight load reads chunk 0 (L1 hits),
+// 64 / 128: MODE.fp_round = +inf / toward zero for the whole kernel (does the MFMA accumulate follow it?  with 16),
 // 16: ONE accumulator set, no rounding-bias cancellation (fp16 form only; results kept: for tools/conv_bias_probe.py).
 #ifndef DCS_X3W_EXP
 #define DCS_X3W_EXP 0
@@ -1481,6 +1482,14 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
   }
   __syncthreads();
 
+#if DCS_X3W_EXP & 64
+  __builtin_amdgcn_s_setreg(2049, 1);      // experiment: fp32 rounding mode +inf -- does the MFMA's accumulate follow MODE?
+  __builtin_amdgcn_s_setreg(2177, 1);
+#endif
+#if DCS_X3W_EXP & 128
+  __builtin_amdgcn_s_setreg(2049, 3);      // ... toward zero
+  __builtin_amdgcn_s_setreg(2177, 3);
+#endif
   const int kch = g.K >> 4;
   const int nch = 9 * kch;
   const int jt0 = (co0 >> 5) + wn * TN;                            // first 32-row weight tile of this wave
@@ -1628,6 +1637,150 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
                                                  mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb, true);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The 7x7 / stride 2 / pad 3 stem forward (14-tap form, ops.geom_stem_fwd) with the INPUT PATCH resident in LDS -- the
+// counterpart of conv3x3_x3w_kernel for the one layer whose K is a filter row instead of a channel range (round 3; fp16
+// two-piece form only).  A block computes 8 rows x 32 pixels x 64 channels.  The (2*8+5) x 70-pixel patch of the NHWC4
+// image is loaded ONCE (the per-tap kernel re-read every input pixel ~12x through L1, one LDS staging pass and one barrier
+// per tap), split into two fp16 pieces of x * 2^X2H_KX and kept as two planes [row][pixel][4 channels]: the 16 k-values of
+// tap (r, c) for output pixel (oy, ox) are the 4 pixels 2 ox - 3 + 4 c .. + 3 of input row 2 oy - 3 + r, i.e. 32
+// contiguous bytes of a plane whose address advances by 16 B per output pixel -- a lane's MFMA A fragment (k = 8 h .. 8 h + 7)
+// is one aligned ds_read_b128, the 64 lanes of a wave read one contiguous run (conflict-free).  Pixel slot 8 of a filter row
+// carries zero weights (ops.pack_stem_weight); its data is real image data or hardware zero fill, never LDS garbage.
+// Weight fragments straight from global memory in the fragment-major split image of the packed [64][7][8][4] weight
+// (dcs_split_weight_frag in its fp16 form with wstride = 224: chunk = tap), two accumulator sets over the tap parity with the
+// sign-flipped copy (rounding-bias cancellation), no barrier inside the loop.
+__device__ __forceinline__
+void stem7_h2_body(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, float* __restrict__ dst,
+                   const DcsConvGeom& g, const int accumulate, float* __restrict__ stats, const unsigned neg_off,
+                   const BlkId bi) {
+  constexpr int TH = 8, BM = 256, BN = 64, WM = 4, TM = 2, TN = 2, NP = 2, J = 2, NTAP = 14;
+  constexpr int PR = 2 * TH + 5, PW = 70;                  // patch rows, pixels per row
+  constexpr int PROWB = PW * 8, PLANE = PR * PROWB;        // bytes: 4 fp16 per pixel and piece
+  constexpr int A_BYTES = NP * PLANE;
+  constexpr int EPI_FLOATS = 4 * 32 * (TN * 32 + 4) + WM * BN * 2;
+  constexpr int SMEM_FLOATS = (A_BYTES / 4) > EPI_FLOATS ? (A_BYTES / 4) : EPI_FLOATS;
+  constexpr int NH = (PR * PW + 255) / 256;
+  static_assert(PROWB % 16 == 0 && PLANE % 16 == 0, "fragment reads must stay 16-byte aligned");
+
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+  __shared__ long long rowoff[BM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wm = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const float x2h_in = (float)(1 << X2H_KX), x2h_out = 1.f / (float)(1 << (X2H_KX + X2H_KW));
+
+  const int mtile = dcs_xcd_remap(bi.x, bi.nx);
+  const int tpx = g.TX >> 5, tpy = g.TY / TH;
+  const int n = mtile / (tpx * tpy);
+  const int trem = mtile - n * (tpx * tpy);
+  const int y0 = (trem / tpx) * TH, x0 = (trem % tpx) << 5;
+  {
+    const int ry = tid >> 5, px = tid & 31;
+    rowoff[tid] = (((long long)n * g.DH + (y0 + ry)) * g.DW + (x0 + px)) * g.dst_cstride;
+  }
+  const long long img_elems = (long long)g.SH * g.SW * 4;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n * img_elems, img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wfrag), 2ll * NTAP * J * NP * 1024);
+
+  // the patch: global -> registers -> two fp16 pieces -> LDS, once
+  float4 rh[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int e = tid + 256 * j;
+    const int pr = e / PW, pc = e - pr * PW;
+    const int iy = 2 * y0 - 3 + pr, ix = 2 * x0 - 3 + pc;
+    const bool ok = e < PR * PW && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+    rh[j] = bld4(rsA, ok ? (unsigned)((iy * g.SW + ix) * 4) * 4u : OOB);
+  }
+  const unsigned lane16 = (unsigned)lane * 16u;
+  bf16x8 fb[2][TN][NP];
+  auto load_w = [&](auto S, int t) {    // tap t = weight chunk t; odd taps come from the sign-flipped copy
+    constexpr int s_ = decltype(S)::value;
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned off = (unsigned)(((t * J + b) * NP + p) * 1024) + lane16 + (s_ ? neg_off : 0u);
+        fb[s_][b][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+      }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+  load_w(P0{}, 0);
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int e = tid + 256 * j;
+    if (NH * 256 != PR * PW && e >= PR * PW) continue;
+    uint2 p1, p2;
+    split2h_quad(rh[j], x2h_in, p1, p2);
+    *reinterpret_cast<uint2*>(sm + e * 8) = p1;
+    *reinterpret_cast<uint2*>(sm + PLANE + e * 8) = p2;
+  }
+
+  f32x16 acc[2][TM][TN];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s_][a][b][r] = 0.f;
+  __syncthreads();
+
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};               // smallest products first
+  // wave wm: output rows 2 wm, 2 wm + 1 of the tile; lane (l31, h): output pixel l31, k half h = patch pixels +2 h, +2 h + 1
+  const unsigned char* Abase = sm + ((4 * wm) * PW + 2 * l31 + 2 * h) * 8;
+  bf16x8 fa[TM][NP];
+  auto step = [&](auto PAR, int t) {
+    constexpr int par = decltype(PAR)::value;
+    const unsigned char* Ab = Abase + ((t >> 1) * PW + 4 * (t & 1)) * 8;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p)
+#pragma unroll
+      for (int a = 0; a < TM; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + a * 2 * PROWB + p * PLANE);
+    if (t + 1 < NTAP) load_w(std::integral_constant<int, 1 - par>{}, t + 1);
+#pragma unroll
+    for (int term = 0; term < 3; ++term)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[par][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a][PA[term]]),
+                                                                  __builtin_bit_cast(f16x8, fb[par][b][PB[term]]),
+                                                                  acc[par][a][b], 0, 0, 0);
+  };
+#pragma unroll
+  for (int t = 0; t < NTAP; t += 2) {
+    step(P0{}, t);
+    step(P1{}, t + 1);
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][a][b][r] = (acc[0][a][b][r] - acc[1][a][b][r]) * x2h_out;
+  __syncthreads();                         // the patch is dead: the epilogue reuses its LDS
+
+  conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, nullptr, dst, g.dst_cstride, g.Cout, 0, accumulate, stats,
+                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, 0, BnBwdEpi{nullptr, nullptr, nullptr, 0},
+                                                 true);
+}
+
+// geometries stem7_h2_kernel covers: the 14-tap stem form of ops.geom_stem_fwd on 8 x 32-pixel output tiles
+bool stem7_eligible(const DcsConvGeom* g) {
+  if (!g->stem || g->ntaps != 14 || g->sy != 2 || g->sx != 2 || g->dsy != 1 || g->dsx != 1 || g->dy0 || g->dx0) return false;
+  if (g->Cout != 64 || g->wstride != 224 || g->src_cstride != 4 || (g->TX & 31) || (g->TY & 7)) return false;
+  if (g->DH != g->TY || g->DW != g->TX || g->SH < 2 * g->TY - 1 || g->SW < 2 * g->TX - 1) return false;
+  for (int t = 0; t < 14; ++t)
+    if (g->offy[t] != t / 2 - 3 || g->offx[t] != -3 + 4 * (t & 1) || g->wofs[t] != (t / 2) * 32 + 16 * (t & 1)) return false;
+  return (long long)g->SH * g->SW * 16 < 0x7FFFFFFFll;
+}
+
 // w [rows][wstride] fp32 -> fragment-major split image (see conv3x3_x3w_kernel): unit (((c*J + j)*3 + p)*2 + h)*32 + r
 // (16 bytes) = piece p of row 32j + r, channels 16c + 8h .. +7; rows beyond `rows` are zero; a sign-flipped copy follows.
 __global__ void split_weight_frag_kernel(const float* __restrict__ w, u32x4* __restrict__ out, const int rows,
@@ -1765,6 +1918,20 @@ void conv3x3_x3w_multi_kernel(const GatherMulti P) {
                                BlkId{rel, s.nbx, 0}, s.src_max);
 }
 
+__global__ __launch_bounds__(256, 2)
+void stem7_h2_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, float* __restrict__ dst,
+                     const DcsConvGeom g, const int accumulate, float* __restrict__ stats, const unsigned neg_off) {
+  stem7_h2_body(src, wfrag, dst, g, accumulate, stats, neg_off, DCS_BLK);
+}
+__global__ __launch_bounds__(256, 2)
+void stem7_h2_multi_kernel(const GatherMulti P) {
+  const int lv = multi_level(P);
+  const GatherSub& s = P.s[lv];
+  const int rel = (int)blockIdx.x - s.blk0;
+  if (rel >= s.nblk) return;
+  stem7_h2_body(s.src, s.w, s.dst, P.g[lv], s.accumulate, s.stats, s.neg_off, BlkId{rel, s.nbx, 0});
+}
+
 template <int BT, int NP = 3>
 __global__ __launch_bounds__(256, 2)
 void conv_wgrad_x3_kernel(const float* __restrict__ src, const float* __restrict__ dy, float* __restrict__ slab,
@@ -1853,7 +2020,7 @@ extern "C" int dcs_split_weight_h2(const float* w, void* out, int64_t rows, int 
 namespace {
 
 // ---- launch plans: validation + kernel choice of one (sub-)launch, shared by the single and the multi entries -----------
-enum GatherKid { GK_X3W_64, GK_X3W_128, GK_X2H_64, GK_X2H_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64,
+enum GatherKid { GK_X3W_64, GK_X3W_128, GK_X2H_64, GK_X2H_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64, GK_STEM7,
                  GK_H2 = 32 /* flag: the per-tap kernels in their fp16 two-piece form */ };
 struct GatherPlan { int kid; DcsConvGeom g; GatherSub s; unsigned nbx, nby; };
 
@@ -1933,6 +2100,22 @@ int plan_x3w(const DcsGatherLaunch& a, GatherPlan& P) {
   if (rc != DCS_OK) return rc;
   DCS_CHECK_ARG(a.src && a.wgt && a.dst && dcs_aligned16(a.src) && dcs_aligned16(a.wgt) && geom->dst_cstride >= geom->Cout);
   DCS_CHECK_ARG(a.nsplit <= 1);
+  if (geom->stem) {                       // the 7x7 stem forward with its input patch in LDS (fp16 two-piece form only)
+    if (!stem7_eligible(geom) || !(a.accumulate & DCS_ACC_FP16X2) || a.bias || a.pro || a.bn_y || a.src_max)
+      return DCS_E_UNSUPPORTED;
+    DCS_CHECK_ARG((a.accumulate & ~(1 | DCS_ACC_FP16X2)) == 0 && !(a.stats && (a.accumulate & 1)));
+    const long long M = (long long)geom->N * geom->TY * geom->TX;
+    DCS_CHECK_ARG(M < 0x7FFFFF00ll && geom->dst_cstride >= 64);
+    P.g = *geom;
+    P.s = GatherSub{a.src, reinterpret_cast<const unsigned char*>(a.wgt), nullptr, a.dst, a.stats, nullptr,
+                    BnBwdEpi{nullptr, nullptr, nullptr, 0}, 0ll,
+                    (a.accumulate & 1) | (dcs_streams(M * geom->dst_cstride * 4) ? 2 : 0), 1, 0, 2,
+                    (unsigned)(14 * 2 * 2 * 1024), 0, 0, 0, nullptr};
+    P.kid = GK_STEM7;
+    P.nbx = (unsigned)(M / 256);
+    P.nby = 1;
+    return DCS_OK;
+  }
   const int bn_ = geom->Cout > 64 ? 128 : 64;
   const int th = bn_ == 64 ? 8 : 4;
   if (geom->Cout <= 32 || (geom->wstride & 15) || !conv3x3_halo_eligible(geom, th)) return DCS_E_UNSUPPORTED;
@@ -1980,6 +2163,9 @@ int launch_gather_one(const GatherPlan& P, hipStream_t s) {
     case GK_X2H_128:
       hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
                          P.s.src_max);
+      break;
+    case GK_STEM7:
+      hipLaunchKernelGGL(stem7_h2_kernel, grid, blk, 0, s, P.s.src, P.s.w, P.s.dst, P.g, P.s.accumulate, P.s.stats, P.s.neg_off);
       break;
     case GK_HALO_64:
       hipLaunchKernelGGL((conv3x3_x3_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro);
@@ -2039,6 +2225,7 @@ int launch_gather_multi(const GatherPlan* const* plans, int n, hipStream_t s) {
     case GK_X3W_128: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4>), grid, blk, 0, s, mp); break;
     case GK_X2H_64: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<64, 8, 2>), grid, blk, 0, s, mp); break;
     case GK_X2H_128: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4, 2>), grid, blk, 0, s, mp); break;
+    case GK_STEM7: hipLaunchKernelGGL(stem7_h2_multi_kernel, grid, blk, 0, s, mp); break;
     case GK_STEM_256: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, true>), grid, blk, 0, s, mp); break;
     case GK_STEM_128: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, true>), grid, blk, 0, s, mp); break;
     case GK_128: hipLaunchKernelGGL(conv_gather_x3_multi_kernel<128>, grid, blk, 0, s, mp); break;

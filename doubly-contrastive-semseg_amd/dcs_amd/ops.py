@@ -524,12 +524,28 @@ def x3w_ok(g):
     return ok and os.environ.get("DCS_X3W", "1") != "0" and os.environ.get("DCS_X3_HALO", "1") == "1"
 
 
+def stem7_ok(g):
+    """The 7x7 stem forward (14-tap form) on 8 x 32-pixel output tiles with at least 256 of them runs the kernel that keeps
+    its input patch in LDS (csrc/conv_split.hip, stem7_h2_kernel; fp16 two-piece form).  DCS_STEM7=0: the per-tap kernel."""
+    ok = getattr(g, "_stem7", None)
+    if ok is None:
+        ok = bool(g.stem and g.ntaps == 14 and g.Cout == 64 and g.wstride == 224 and g.TX % 32 == 0 and g.TY % 8 == 0 and
+                  g.DH == g.TY and g.DW == g.TX and g.SH >= 2 * g.TY - 1 and g.SW >= 2 * g.TX - 1 and
+                  g.N * g.TY * g.TX // 256 >= 256 and g.SH * g.SW * 16 < 2 ** 31)
+        g._stem7 = ok
+    return ok and os.environ.get("DCS_STEM7", "1") != "0"
+
+
 def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None, ns=1, slab_n=0, fwd=False):
     """One launch of the gather kernel family.  bnb = (y, mask, bn record, relu) or None.  fwd: a forward convolution
     (activations x weights: operands of known magnitude -> the fp16 two-piece kernel where it applies); a data gradient
     takes that kernel when its source carries the device word with its maximum (bn_bwd's dy: ``_dcs_max``)."""
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
-    if ns == 1 and x3_ok(g) and x3w_ok(g):
+    if (ns == 1 and g.stem and fwd and bias is None and pro is None and bnb is None and x3_ok(g) and stem7_ok(g) and
+            _x2h_forward[0] and x2h_on()):
+        _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag_h2(wgt)), None, _p(dst), g, accumulate | ACC_FP16X2,
+              _p(stats), None, None, None, None, 0, None, _stream())
+    elif ns == 1 and x3_ok(g) and x3w_ok(g):
         smax = None if fwd else getattr(src, "_dcs_max", None)
         if ((fwd and _x2h_forward[0]) or smax is not None) and x2h_on():
             _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,

@@ -142,6 +142,44 @@ def test_stem_conv_and_wgrad(ops, N, H, W):
     close(got, E.unpack_stem_weight(dref, w), 5e-5, "stem wgrad")
 
 
+@pytest.mark.parametrize("N,H,W", [(8, 128, 256), (6, 160, 320), (16, 95, 191), (10, 112, 256)])
+def test_stem_forward_with_the_patch_in_lds(ops, monkeypatch, N, H, W):
+    """stem7_h2_kernel (7x7 / stride 2 forward, input patch resident in LDS, fp16 two-piece products) against a float64
+    convolution: error <= 1.5x the exact-fp32 MFMA kernel's, fused BatchNorm statistics, image borders (odd sizes: the last
+    input row / column is missing); bitwise the per-tap fp16 kernel (DCS_STEM7=0), whose sums it forms in the same order."""
+    ops.new_step(True)
+    p = torch.zeros(N, H, W, 4)
+    p[..., :3] = rnd(N, H, W, 3, seed=191) * 2.5
+    w = cl(rnd(64, 3, 7, 7, seed=192, scale=0.1))
+    wp = ops.pack_stem_weight(cl(w.to(DEV)))
+    pd = p.to(DEV)
+    g = ops.geom_stem_fwd(N, H, W)
+    if (H + 1) // 2 % 8 or (W + 1) // 2 % 32:
+        assert not ops.stem7_ok(g)                       # 48 x 96 outputs: not a multiple of the 8 x 32 tile -> per-tap kernel
+        return
+    assert ops.stem7_ok(g)
+    ref = torch.nn.functional.conv2d(p[..., :3].permute(0, 3, 1, 2).double(), w.double(), None, 2, 3).permute(0, 2, 3, 1)
+    y, sums = ops.stem_conv(pd, wp, want_stats=True)
+    y2 = ops.stem_conv(pd, wp)
+    monkeypatch.setenv("DCS_STEM7", "0")
+    ytap = ops.stem_conv(pd, wp)
+    monkeypatch.setenv("DCS_CONV_X3", "0")
+    y32 = ops.stem_conv(pd, wp)
+    monkeypatch.delenv("DCS_CONV_X3"); monkeypatch.delenv("DCS_STEM7")
+    assert torch.equal(y, y2)
+    scale = float(ref.abs().max())
+    e_p, e_t, e_32 = (float((t.cpu().double() - ref).abs().max()) / scale for t in (y, ytap, y32))
+    err = y.cpu().double() - ref
+    bal = float(err.sum() / err.abs().sum())
+    print(f"stem fwd {N}x{H}x{W}: max-rel patch kernel {e_p:.3e} per-tap {e_t:.3e} fp32 {e_32:.3e}; sign balance {bal:+.3f}; "
+          f"bitwise the per-tap kernel: {torch.equal(y, ytap)}")
+    assert e_p <= 1.5 * e_32 + 1e-7 and abs(bal) < 0.05
+    assert torch.equal(y, ytap)                 # same products in the same order as the per-tap fp16 kernel: bitwise
+    mom = E.colsum(ref.reshape(-1, 64).float(), moments=True)
+    close(sums[0, 0], mom[0, 0], 1e-5, "stem fused BN statistics: mean")
+    close(sums[0, 1], mom[0, 1], 1e-5, "stem fused BN statistics: variance")
+
+
 def test_linear_and_transpose(ops):
     x, w, b = rnd(37, 128, seed=12), rnd(128, 128, seed=13, scale=0.1), rnd(128, seed=14)
     close(ops.linear(x.to(DEV), w.to(DEV), b.to(DEV)), E.linear(x, w, b), what="linear")
