@@ -12,7 +12,7 @@ import sys
 from collections import defaultdict
 
 # single launches and the level-batched *_multi launches of every family
-GROUPS = {"conv_gather": ("conv_gather_kernel", "conv_gather_x3_", "conv3x3_x3_kernel", "conv3x3_x3w_"),
+GROUPS = {"conv_gather": ("conv_gather_kernel", "conv_gather_x3_", "conv3x3_x3_kernel", "conv3x3_x3w_", "stem7_h2_"),
           "conv_wgrad": ("conv_wgrad", "stem_wgrad")}
 
 
