@@ -347,8 +347,9 @@ void upsample_add_kernel(const float* __restrict__ x, const float* __restrict__ 
 // yields); border rows / columns and other ratios take the generic scan.
 __global__ __launch_bounds__(256)
 void upsample_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, int N, int IH, int IW, int OH, int OW,
-                         int C, int accumulate, int fy, int fx) {
+                         int C, int accumulate, int fy, int fx, unsigned* __restrict__ maxabs) {
   const int C4 = C >> 2;
+  float mx = 0.f;
   const long long total = (long long)N * IH * IW * C4;
   const float sy = (float)IH / (float)OH, sx = (float)IW / (float)OW;
   const float inv_fy = fy > 0 ? 1.f / (float)fy : 0.f, inv_fx = fx > 0 ? 1.f / (float)fx : 0.f;
@@ -389,6 +390,18 @@ void upsample_bwd_kernel(const float* __restrict__ g, float* __restrict__ gx, in
     }
     if (accumulate) acc = f4add(acc, ld4(gx + i * 4));
     st4(gx + i * 4, acc);
+    mx = fmaxf(fmaxf(mx, fmaxf(fabsf(acc.x), fabsf(acc.y))), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+  }
+  if (maxabs) {                          // max |gx| as float bits, one filtered atomic per block (see bn_bwd_apply_kernel)
+    __shared__ float s_mx[4];
+    mx = dcs_wave_max(mx);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      mx = fmaxf(fmaxf(s_mx[0], s_mx[1]), fmaxf(s_mx[2], s_mx[3]));
+      const unsigned bits = __float_as_uint(mx);
+      if (bits > __hip_atomic_load(maxabs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxabs, bits);
+    }
   }
 }
 
@@ -624,12 +637,12 @@ extern "C" int dcs_upsample_add_stats(const float* x, const float* s0, const flo
 }
 
 extern "C" int dcs_upsample_bwd(const float* g, float* gx, int N, int IH, int IW, int OH, int OW, int C, int accumulate,
-                                void* stream) {
+                                uint32_t* maxabs, void* stream) {
   DCS_CHECK_ARG(g && gx && N > 0 && IH > 0 && IW > 0 && OH > 0 && OW > 0 && C > 0 && (C & 3) == 0);
   const long long total = (long long)N * IH * IW * (C / 4);
   auto pow2_factor = [](int out, int in) { const int f = out / in; return (out % in == 0 && (f & (f - 1)) == 0 && f <= 16) ? f : 0; };
   hipLaunchKernelGGL(upsample_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, dcs_stream(stream), g, gx, N, IH, IW, OH, OW,
-                     C, accumulate, pow2_factor(OH, IH), pow2_factor(OW, IW));
+                     C, accumulate, pow2_factor(OH, IH), pow2_factor(OW, IW), maxabs);
   DCS_LAUNCH_RET();
 }
 

@@ -85,7 +85,7 @@ SIGNATURES = {
     "dcs_bn_pool_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "dcs_upsample_add": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dcs_upsample_add_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
-    "dcs_upsample_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
+    "dcs_upsample_bwd": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P],
     "dcs_upsample_to_nchw": [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_upsample_to_nchw_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],
     "dcs_seg_loss": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _I, _I, _P],

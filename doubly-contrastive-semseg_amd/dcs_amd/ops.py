@@ -1003,7 +1003,10 @@ def upsample_bwd(g, IH, IW, out=None, accumulate=False):
     if out is None:
         out = torch.empty((N, IH, IW, Cc), device=g.device, dtype=_F32)
         accumulate = False
-    _call("dcs_upsample_bwd", _p(_req(g)), _p(out), N, IH, IW, OH, OW, Cc, 1 if accumulate else 0, _stream())
+    smax = _max_slot(g.device) if (g.is_cuda and x2h_on() and not accumulate) else None    # max |out| rides along (tag_max)
+    _call("dcs_upsample_bwd", _p(_req(g)), _p(out), N, IH, IW, OH, OW, Cc, 1 if accumulate else 0, _p(smax), _stream())
+    if smax is not None:
+        out._dcs_max = smax
     return out
 
 

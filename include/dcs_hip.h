@@ -273,9 +273,10 @@ int dcs_upsample_add(const float* x, const float* s0, const float* s1, const flo
  * dcs_colsum_final(partial, out, 1, groups, C, 1, count). */
 int dcs_upsample_add_stats(const float* x, const float* s0, const float* s1, const float* s2, float* t, float* partial,
                            int groups, int N, int IH, int IW, int OH, int OW, int C, void* stream);
-/* adjoint of the bilinear part: gx[n,iy,ix,c] (+)= sum_o w(o,i) g[n,oy,ox,c]. */
+/* adjoint of the bilinear part: gx[n,iy,ix,c] (+)= sum_o w(o,i) g[n,oy,ox,c].  maxabs (may be null): raised to the bits of
+ * max |gx| like dcs_bn_bwd_apply's dy_maxabs (the decoder's next blend convolution scales its gradient by it). */
 int dcs_upsample_bwd(const float* g, float* gx, int N, int IH, int IW, int OH, int OW, int C,
-                     int accumulate, void* stream);
+                     int accumulate, uint32_t* maxabs, void* stream);
 /* network/utils.py:8 on the logits: x NHWC [N,IH,IW,cs] (first C channels) -> out NCHW [N,C,OH,OW]. */
 int dcs_upsample_to_nchw(const float* x, float* out, int N, int IH, int IW, int cs, int C, int OH, int OW,
                          void* stream);

@@ -288,7 +288,10 @@ def test_upsample_add_and_adjoint(ops, IH, IW, OH, OW):
         close(ops.upsample_add(x.to(DEV), [s.to(DEV) for s in sk[:n]], OH, OW), E.upsample_add(x, sk[:n], OH, OW), 2e-6,
               f"upsample_add {n}")
     g = rnd(N, OH, OW, C, seed=35)
-    close(ops.upsample_bwd(g.to(DEV), IH, IW), E.upsample_bwd(g, IH, IW), 1e-5, "upsample bwd")
+    gx = ops.upsample_bwd(g.to(DEV), IH, IW)
+    close(gx, E.upsample_bwd(g, IH, IW), 1e-5, "upsample bwd")
+    if ops.x2h_on():                   # the maximum word the fp16 two-piece consumers scale by
+        assert int(gx._dcs_max.item()) == int(gx.abs().max().view(torch.int32).item())
     base = rnd(N, IH, IW, C, seed=36)
     acc = base.to(DEV).clone()
     ops.upsample_bwd(g.to(DEV), IH, IW, out=acc, accumulate=True)
