@@ -139,7 +139,11 @@ int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, 
  * wfrag must then come from dcs_split_weight_frag_h2 (unit (((c*J + j)*2 + p)*2 + h)*32 + r; 2 x wstride/16 x J x 2 KiB).
  * src_max (nullable, DCS_ACC_FP16X2 only): device word holding the bit pattern of max |src| (as dcs_bn_bwd_apply's
  * dy_maxabs leaves it).  The kernel then scales src by the power of two that puts that maximum into [2^13, 2^14) instead of
- * 2^2: data gradients (src = dy, magnitudes of 1e-3 .. 1e-10) use the same kernel with an exact, per-tensor scale. */
+ * 2^2: data gradients (src = dy, magnitudes of 1e-3 .. 1e-10) use the same kernel with an exact, per-tensor scale.
+ * Stem (network/backbone/resnet_pyramid.py:110-112, 7x7 / stride 2 / pad 3 on the NHWC4 image): with the 14-tap stem geometry,
+ * accumulate | DCS_ACC_FP16X2, wfrag = dcs_split_weight_frag_h2(packed [64][7][8][4] weight, 64, 224), no bias / pro / bn_*
+ * / src_max, and an output map of whole 8 x 32-pixel tiles the same entry runs the stem forward with its input patch
+ * resident in LDS (stem7_h2_kernel); other stem launches: DCS_E_UNSUPPORTED (use dcs_conv_gather_x3). */
 #define DCS_ACC_FP16X2 16
 int dcs_split_weight_frag(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_split_weight_frag_h2(const float* w, void* out, int64_t rows, int wstride, void* stream);
