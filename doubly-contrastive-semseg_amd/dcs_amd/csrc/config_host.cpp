@@ -21,13 +21,14 @@ DcsConfig from_env() {
   c.conv_bk16 = std::getenv("DCS_CONV_BK16") ? 1 : 0;
   c.wgrad_ch32 = std::getenv("DCS_WGRAD_CH32") ? 1 : 0;
   c.contrast_fused = env_int("DCS_CONTRAST_FUSED", 1);
+  c.x3w_db = env_int("DCS_X3W_DB", 1);
   return c;
 }
 struct Entry { const char* name; int DcsConfig::*field; };
 const Entry kEntries[] = {
     {"bn_nt", &DcsConfig::bn_nt}, {"nt_min_mb", &DcsConfig::nt_min_mb}, {"x3_bm128", &DcsConfig::x3_bm128},
     {"x3_halo", &DcsConfig::x3_halo}, {"wgrad_roll", &DcsConfig::wgrad_roll}, {"conv_bk16", &DcsConfig::conv_bk16},
-    {"wgrad_ch32", &DcsConfig::wgrad_ch32}, {"contrast_fused", &DcsConfig::contrast_fused},
+    {"wgrad_ch32", &DcsConfig::wgrad_ch32}, {"contrast_fused", &DcsConfig::contrast_fused}, {"x3w_db", &DcsConfig::x3w_db},
 };
 }  // namespace
 

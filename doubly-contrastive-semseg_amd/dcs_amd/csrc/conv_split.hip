@@ -1638,6 +1638,210 @@ void conv3x3_x3w_body(const float* __restrict__ src, const unsigned char* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3x3_x3w_kernel<.., 2> with the halo DOUBLE-BUFFERED in LDS (round 3; fp16 two-piece form only).  Timing experiments put
+// 5-10 % of that kernel into the halo replacement: every nine taps all waves stop at a barrier, split and write the next 16
+// channels' halo, stop at a second barrier.  Here a chunk's nine taps are unrolled (two variants for the chunk's starting
+// parity), the halo of chunk kc + 1 is written into the OTHER buffer one staging slot per tap behind the MFMAs of chunk kc,
+// the loads of chunk kc + 2 go out as soon as the registers are free (unconditionally -- out of range past the end -- so
+// that the compiler counts the loads in flight instead of draining them), and ONE barrier per chunk remains.  Same
+// products in the same order: bitwise the single-buffered kernel.
+// DCS_DB_VAR (compile time): where a tap's staging slot sits -- bit 0: in front of the tap's MFMAs, bit 1: no scheduling barrier
+// between taps.  Measured (conv_bench, 64 / 128 / 256 / 512 channels, TF): 0: 258 / 367-375 / 400 / 403, 1: 260 / 367-376 / 405 / 408,
+// 2: 258 / 361-367 / 397 / 399, 3: 267 / 368-377 / 402 / 405 (single-buffered kernel on that box: 253 / 352-355 / 375 / 376 + 3 %).
+#ifndef DCS_DB_VAR
+#define DCS_DB_VAR 3
+#endif
+template <int BN, int TH>
+__device__ __forceinline__
+void conv3x3_x3w_db_body(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
+                         float* __restrict__ dst, const DcsConvGeom& g, const int accumulate, const int ntiles,
+                         float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
+                         const unsigned neg_off, const BlkId bi, const unsigned* __restrict__ src_max) {
+  constexpr int NP = 2;
+  constexpr int BM = 32 * TH, HWD = 34, HROWS = (TH + 2) * HWD;
+  constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = 2, TN = BN / (WN * 32);
+  constexpr int ROWB = 80;
+  constexpr int A_BYTES = HROWS * ROWB;
+  constexpr int EPI_FLOATS = 4 * 32 * (TN * 32 + 4) + WM * BN * 2;
+  constexpr int SMEM_FLOATS = (2 * A_BYTES / 4) > EPI_FLOATS ? (2 * A_BYTES / 4) : EPI_FLOATS;
+  constexpr int NH = (HROWS * 4 + 255) / 256;
+  static_assert(TM * WM * 32 == BM && (BN == 64 || BN == 128) && NH < 9, "unsupported tile");
+
+  __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
+  unsigned char* const sm = reinterpret_cast<unsigned char*>(smem);
+  __shared__ long long rowoff[BM];
+  __shared__ int s_ho[9], s_wc[9];
+  __shared__ __attribute__((aligned(16))) float s_pro[2 * DCS_PRO_MAXK];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wid = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wid / WN, wn = wid % WN;
+  const int lcol4 = tid & 3;
+  const bool has_pro = pro != nullptr;
+  if (has_pro)
+    for (int e = tid; e < 2 * g.K; e += 256) s_pro[(e < g.K ? 0 : DCS_PRO_MAXK - g.K) + e] = pro[e];
+  float x2h_in = (float)(1 << X2H_KX), x2h_out = 1.f / (float)(1 << (X2H_KX + X2H_KW));
+  if (src_max != nullptr) {
+    const unsigned mbits = __builtin_amdgcn_readfirstlane(*src_max);
+    const int e = (int)((mbits >> 23) & 0xffu) - 126;               // max = f 2^e, f in [0.5, 1)
+    int k = (mbits >> 23) == 0u ? 0 : 14 - e;
+    k = k < -100 ? -100 : (k > 100 ? 100 : k);
+    x2h_in = __uint_as_float((unsigned)(127 + k) << 23);
+    x2h_out = __uint_as_float((unsigned)(127 - k - X2H_KW) << 23);
+  }
+
+  const int bid = dcs_xcd_remap(bi.x, bi.nx);
+  const int ntile = bid % ntiles, mtile = bid / ntiles;
+  const int co0 = ntile * BN;
+  const int tpx = g.TX >> 5, tpy = g.TY / TH;
+  const int n = mtile / (tpx * tpy);
+  const int trem = mtile - n * (tpx * tpy);
+  const int y0 = (trem / tpx) * TH, x0 = (trem % tpx) << 5;
+
+  if (tid < BM) {
+    const int ry = tid >> 5, px = tid & 31;
+    rowoff[tid] = (((long long)n * g.DH + (y0 + ry)) * g.DW + (x0 + px)) * g.dst_cstride;
+  }
+  if (tid < 9) {
+    s_ho[tid] = (g.offy[tid] * HWD + g.offx[tid]) * ROWB;
+    s_wc[tid] = g.wofs[tid] >> 4;                                 // first K chunk of the tap
+  }
+  const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
+  const int wchunks = g.wstride >> 4;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n * img_elems, img_elems * 4);
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wfrag), 2ll * wchunks * J * NP * 1024);
+
+  int h_off[NH];
+  float lim[NH];
+#pragma unroll
+  for (int j = 0; j < NH; ++j) {
+    const int hrow = (tid + 256 * j) >> 2;
+    const int hy = hrow / HWD, hx = hrow - hy * HWD;
+    const int iy = y0 + hy - 1, ix = x0 + hx - 1;
+    const bool ok = hrow < HROWS && (unsigned)iy < (unsigned)g.SH && (unsigned)ix < (unsigned)g.SW;
+    h_off[j] = ok ? (iy * g.SW + ix) * g.src_cstride + lcol4 * 4 : -1;
+    lim[j] = ok ? __builtin_inff() : 0.f;
+  }
+  __syncthreads();
+
+  const int kch = g.K >> 4;
+  const int nch = 9 * kch;
+  const int jt0 = (co0 >> 5) + wn * TN;                            // first 32-row weight tile of this wave
+  const unsigned lane16 = (unsigned)lane * 16u;
+
+  float4 rh[NH];
+  auto load_halo = [&](int kc) {                                   // unconditional: past the last chunk every lane is out of range
+#pragma unroll
+    for (int j = 0; j < NH; ++j) rh[j] = bld4(rsA, (h_off[j] >= 0 && kc < kch) ? (unsigned)(h_off[j] + kc * 16) * 4u : OOB);
+  };
+  auto store_slot = [&](int j, int kc, unsigned char* buf) {
+    const int hrow = (tid + 256 * j) >> 2;
+    if (NH * 64 != HROWS && hrow >= HROWS) return;
+    float4 v = rh[j];
+    if (has_pro) {
+      const float4 p_sc = ld4(&s_pro[kc * 16 + lcol4 * 4]), p_sh = ld4(&s_pro[DCS_PRO_MAXK + kc * 16 + lcol4 * 4]);
+      v = pro_apply(v, p_sc, p_sh, lim[j]);
+    }
+    unsigned char* q = buf + hrow * ROWB + lcol4 * 8;
+    uint2 p1, p2;
+    split2h_quad(v, x2h_in, p1, p2);
+    *reinterpret_cast<uint2*>(q) = p1;
+    *reinterpret_cast<uint2*>(q + 32) = p2;
+  };
+  bf16x8 fb[2][TN][NP];
+  int lw_kc = 0, lw_t = 0;            // the next weight chunk to load
+  auto load_w = [&](auto S) {         // chunk parity S: odd chunks come from the sign-flipped copy
+    constexpr int s_ = decltype(S)::value;
+    const int c = s_wc[lw_t] + lw_kc;
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) {
+        const unsigned off = (unsigned)(((c * J + jt0 + b) * NP + p) * 1024) + lane16 + (s_ ? neg_off : 0u);
+        fb[s_][b][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsB, off, 0, 0));
+      }
+    if (lw_kc * 9 + lw_t + 1 < nch) { lw_t += 1; if (lw_t == 9) { lw_t = 0; lw_kc += 1; } }
+  };
+  using P0 = std::integral_constant<int, 0>;
+  using P1 = std::integral_constant<int, 1>;
+
+  f32x16 acc[2][TM][TN];
+#pragma unroll
+  for (int s_ = 0; s_ < 2; ++s_)
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[s_][a][b][r] = 0.f;
+
+  load_halo(0);
+  load_w(P0{});                          // chunk 0
+#pragma unroll
+  for (int j = 0; j < NH; ++j) store_slot(j, 0, sm);
+  load_halo(1);
+  __syncthreads();
+
+  constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};               // smallest products first
+  bf16x8 fa[TM][NP];
+  const int a_off = ((wm * 2 + 1) * HWD + l31 + 1) * ROWB + h * 16;
+  // one 16-channel chunk = nine taps, unrolled; START = parity of its first tap (9 is odd: it alternates per chunk)
+  auto chunk = [&](auto START, const int kc) {
+    constexpr int start = decltype(START)::value;
+    const unsigned char* Abase = sm + (kc & 1) * A_BYTES + a_off;
+    unsigned char* const other = sm + ((kc + 1) & 1) * A_BYTES;
+    const bool more = kc + 1 < kch;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      constexpr int dummy = 0; (void)dummy;
+      const int par = (start + t) & 1;
+      const unsigned char* Ab = Abase + s_ho[t];
+#pragma unroll
+      for (int p = NP - 1; p >= 0; --p)
+#pragma unroll
+        for (int a = 0; a < TM; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + a * HWD * ROWB + p * 32);
+      if (par == 0) load_w(P1{}); else load_w(P0{});                // the next tap's weight fragments
+#if DCS_DB_VAR & 1
+      if (t < NH) { if (more) store_slot(t, kc + 1, other); }
+      if (t == NH) load_halo(kc + 2);
+#endif
+#pragma unroll
+      for (int term = 0; term < 3; ++term)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[par][a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[a][PA[term]]),
+                                                                    __builtin_bit_cast(f16x8, fb[par][b][PB[term]]),
+                                                                    acc[par][a][b], 0, 0, 0);
+#if !(DCS_DB_VAR & 1)
+      if (t < NH) { if (more) store_slot(t, kc + 1, other); }       // halo of the next chunk: one staging slot per tap
+      if (t == NH) load_halo(kc + 2);                               // registers free again: the chunk after that
+#endif
+#if !(DCS_DB_VAR & 2)
+      __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+    __syncthreads();
+  };
+  for (int kc = 0; kc < kch; kc += 2) {
+    chunk(P0{}, kc);
+    if (kc + 1 < kch) chunk(P1{}, kc + 1);
+  }
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][a][b][r] = (acc[0][a][b][r] - acc[1][a][b][r]) * x2h_out;
+  // (the last chunk ended with a barrier: the halo is dead, the epilogue reuses its LDS)
+
+  conv_epilogue<BM, BN, TM, TN, WM, SMEM_FLOATS>(acc[0], smem, rowoff, bias, dst, g.dst_cstride, g.Cout, co0, accumulate, stats,
+                                                 mtile, (unsigned long long)g.N * g.TY * g.TX, wm, wn, bnb, true);
+}
+
+// ------------------------------------------------------------------------------------------------
 // The 7x7 / stride 2 / pad 3 stem forward (14-tap form, ops.geom_stem_fwd) with the INPUT PATCH resident in LDS -- the
 // counterpart of conv3x3_x3w_kernel for the one layer whose K is a filter row instead of a channel range (round 3; fp16
 // two-piece form only).  A block computes 8 rows x 32 pixels x 64 channels.  The (2*8+5) x 70-pixel patch of the NHWC4
@@ -1918,6 +2122,25 @@ void conv3x3_x3w_multi_kernel(const GatherMulti P) {
                                BlkId{rel, s.nbx, 0}, s.src_max);
 }
 
+template <int BN, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_x3w_db_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, const float* __restrict__ bias,
+                           float* __restrict__ dst, const DcsConvGeom g, const int accumulate, const int ntiles,
+                           float* __restrict__ stats, const BnBwdEpi bnb, const float* __restrict__ pro, const int J,
+                           const unsigned neg_off, const unsigned* __restrict__ src_max) {
+  conv3x3_x3w_db_body<BN, TH>(src, wfrag, bias, dst, g, accumulate, ntiles, stats, bnb, pro, J, neg_off, DCS_BLK, src_max);
+}
+template <int BN, int TH>
+__global__ __launch_bounds__(256, 2)
+void conv3x3_x3w_db_multi_kernel(const GatherMulti P) {
+  const int lv = multi_level(P);
+  const GatherSub& s = P.s[lv];
+  const int rel = (int)blockIdx.x - s.blk0;
+  if (rel >= s.nblk) return;
+  conv3x3_x3w_db_body<BN, TH>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.bnb, s.pro, s.J, s.neg_off,
+                              BlkId{rel, s.nbx, 0}, s.src_max);
+}
+
 __global__ __launch_bounds__(256, 2)
 void stem7_h2_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wfrag, float* __restrict__ dst,
                      const DcsConvGeom g, const int accumulate, float* __restrict__ stats, const unsigned neg_off) {
@@ -2157,12 +2380,20 @@ int launch_gather_one(const GatherPlan& P, hipStream_t s) {
                          P.s.src_max);
       break;
     case GK_X2H_64:
-      hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
-                         P.s.src_max);
+      if (dcs_config().x3w_db)
+        hipLaunchKernelGGL((conv3x3_x3w_db_kernel<64, 8>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                           P.s.src_max);
+      else
+        hipLaunchKernelGGL((conv3x3_x3w_kernel<64, 8, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                           P.s.src_max);
       break;
     case GK_X2H_128:
-      hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
-                         P.s.src_max);
+      if (dcs_config().x3w_db)
+        hipLaunchKernelGGL((conv3x3_x3w_db_kernel<128, 4>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                           P.s.src_max);
+      else
+        hipLaunchKernelGGL((conv3x3_x3w_kernel<128, 4, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.bnb, P.s.pro, P.s.J, P.s.neg_off,
+                           P.s.src_max);
       break;
     case GK_STEM7:
       hipLaunchKernelGGL(stem7_h2_kernel, grid, blk, 0, s, P.s.src, P.s.w, P.s.dst, P.g, P.s.accumulate, P.s.stats, P.s.neg_off);
@@ -2223,8 +2454,14 @@ int launch_gather_multi(const GatherPlan* const* plans, int n, hipStream_t s) {
   switch (plans[0]->kid) {
     case GK_X3W_64: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<64, 8>), grid, blk, 0, s, mp); break;
     case GK_X3W_128: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4>), grid, blk, 0, s, mp); break;
-    case GK_X2H_64: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<64, 8, 2>), grid, blk, 0, s, mp); break;
-    case GK_X2H_128: hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4, 2>), grid, blk, 0, s, mp); break;
+    case GK_X2H_64:
+      if (dcs_config().x3w_db) hipLaunchKernelGGL((conv3x3_x3w_db_multi_kernel<64, 8>), grid, blk, 0, s, mp);
+      else hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<64, 8, 2>), grid, blk, 0, s, mp);
+      break;
+    case GK_X2H_128:
+      if (dcs_config().x3w_db) hipLaunchKernelGGL((conv3x3_x3w_db_multi_kernel<128, 4>), grid, blk, 0, s, mp);
+      else hipLaunchKernelGGL((conv3x3_x3w_multi_kernel<128, 4, 2>), grid, blk, 0, s, mp);
+      break;
     case GK_STEM7: hipLaunchKernelGGL(stem7_h2_multi_kernel, grid, blk, 0, s, mp); break;
     case GK_STEM_256: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, true>), grid, blk, 0, s, mp); break;
     case GK_STEM_128: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, true>), grid, blk, 0, s, mp); break;

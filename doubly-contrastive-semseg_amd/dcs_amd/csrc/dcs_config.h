@@ -11,6 +11,7 @@ struct DcsConfig {
   int conv_bk16;      // DCS_CONV_BK16   (0)   1 = 16-channel chunks everywhere in the fp32 gather
   int wgrad_ch32;     // DCS_WGRAD_CH32  (0)   1 = 32-pixel chunks in the generic fp32 weight gradient
   int contrast_fused; // DCS_CONTRAST_FUSED (1) 0 = two launches for the small similarity family (A/B, tests)
+  int x3w_db;         // DCS_X3W_DB      (1)   0 = single-buffered halo in the fp16 3x3 kernels (A/B, tests)
 };
 extern DcsConfig g_dcs_config;
 static inline const DcsConfig& dcs_config() { return g_dcs_config; }

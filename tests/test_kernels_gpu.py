@@ -142,6 +142,31 @@ def test_stem_conv_and_wgrad(ops, N, H, W):
     close(got, E.unpack_stem_weight(dref, w), 5e-5, "stem wgrad")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(8, 64, 128, 64, 64), (16, 32, 64, 128, 128), (8, 32, 64, 512, 256), (8, 64, 128, 96, 64)])
+def test_double_buffered_halo_kernel_is_bitwise_the_single_buffered_one(ops, libopt, N, H, W, Cin, Cout):
+    """conv3x3_x3w_db_kernel (halo of the next 16 channels written into a second LDS buffer behind the MFMAs, one barrier per
+    chunk) against conv3x3_x3w_kernel<.., 2>: forward with fused statistics and BatchNorm + ReLU prologue, data gradient with
+    the BatchNorm-backward epilogue and a per-tensor scale -- same products in the same order, so every bit agrees."""
+    assert ops.x3w_ok(ops.geom_fwd(N, H, W, Cin, Cout, 3, 3, 1, 1))
+    ops.new_step(True)
+    x = rnd(N, H, W, Cin, seed=201).to(DEV)
+    w = cl(rnd(Cout, Cin, 3, 3, seed=202, scale=0.05).to(DEV))
+    gi, bi_ = (rnd(Cin, seed=203) * 0.1 + 1).to(DEV), (rnd(Cin, seed=204) * 0.1).to(DEV)
+    bn_i = ops.bn_finalize(ops.colsum(x.reshape(-1, Cin), moments=True), gi, bi_, torch.zeros(Cin, device=DEV),
+                           torch.ones(Cin, device=DEV), N * H * W, True)
+    dy = rnd(N, H, W, Cout, seed=205).to(DEV) * 1e-4
+    ops.tag_max(dy)
+    wpk = ops.pack_dgrad_weight(w)
+    outs = {}
+    for db in (1, 0):
+        libopt("x3w_db", db)
+        y, st = ops.conv_fwd(x, w, 1, 1, want_stats=True, pro=bn_i)
+        gx, sums = ops.conv_dgrad(dy, wpk, (H, W), 1, 1, bnb=(x, None, bn_i, True))
+        outs[db] = (y, st, gx, sums)
+    for a, b in zip(outs[1], outs[0]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("N,H,W", [(8, 128, 256), (6, 160, 320), (16, 95, 191), (10, 112, 256)])
 def test_stem_forward_with_the_patch_in_lds(ops, monkeypatch, N, H, W):
     """stem7_h2_kernel (7x7 / stride 2 forward, input patch resident in LDS, fp16 two-piece products) against a float64
