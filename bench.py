@@ -194,6 +194,7 @@ def roofline(g, wg, args, world):
             "peak_note": "fp32-equivalent speed of light of the launch mix: dense 16-bit MFMA peak 2500 TFLOP/s / 3 (two fp16 "
                          "pieces per operand) or / 6 (three bf16 pieces), fp32 MFMA 157.3; weighted by algorithmic FLOPs",
             "frac_of_fp32_mfma_peak": g["tflops"] / PEAK_FP32_MFMA_TFLOPS,
+            "frac_of_bf16x3_peak": g["tflops"] / PEAK_X3_TFLOPS,       # round 2's yardstick (416.7 TF), for continuity
             "scheme_flop_share": g.get("scheme_flop_share", {}),
             "traffic": pmc_traffic(args, world, "conv_gather"),
             "traffic_unit": "HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, see profiles/README.md)",
