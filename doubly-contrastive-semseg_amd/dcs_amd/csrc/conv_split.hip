@@ -119,7 +119,12 @@ constexpr int X3_ROWB = 112;      // bytes per LDS row
 // NP = 2: the fp16 two-piece form (split2h_quad; weights from dcs_split_weight_h2: 64-byte chunk images): LDS rows of 80 B,
 // three MFMAs per product; src scaled by 2^X2H_KX or, with src_max, by the power of two that puts the tensor's maximum into
 // [2^13, 2^14); the result by the inverse of both scales.
-template <int BN, int BM = 128, bool STEM = false, int NP = 3>
+// WF (round 3, fp16 form): the WEIGHT fragments come straight from global memory in the fragment-major split image of
+// dcs_split_weight_frag_h2 (as in conv3x3_x3w_kernel) instead of being staged through LDS.  With three MFMAs per product
+// the LDS-staged form moves 48 KB through LDS per block and 16-channel step (A + B written, both read back per wave) against
+// 384 MFMA cycles: two blocks per CU sit at the 128 B/clk of the LDS -- the 1x1 and strided layers stood at 180-250 TF
+// whatever their shape.  Only A (the gathered pixels) still passes through LDS; B costs four 1-KiB loads per wave and step.
+template <int BN, int BM = 128, bool STEM = false, int NP = 3, bool WF = false>
 __device__ __forceinline__
 void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
                            const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom& g,
@@ -132,12 +137,14 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
   // 128 x 128 and 128 x 64 tiles: waves 2 x 2; 256 x 64 (64-channel layers of large maps): waves 4 x 1, so that a wave
   // still owns a 64 x 64 sub-tile (24 MFMAs per chunk against 5-6 staging slots instead of 12 against 4)
   constexpr int WN = BM == 256 ? 1 : 2, WM = 4 / WN, TM = BM / (WM * 32), TN = BN / (WN * 32);
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = WF ? 0 : BN * ROWB;
   constexpr int EPI_FLOATS_ = 4 * 32 * (TN * 32 + 4) + WM * BN * 2;                 // what conv_epilogue stages
   constexpr int SMEM_FLOATS = 2 * (A_BYTES + B_BYTES) / 4 > EPI_FLOATS_ ? 2 * (A_BYTES + B_BYTES) / 4 : EPI_FLOATS_;
   constexpr int NA = BM / 64;                // A slots per thread: 64 rows x 4 float4 each
-  constexpr int NB = (BN * WU + 255) / 256;  // B slots per thread: 16-byte pieces of the row images
+  constexpr int NB = WF ? 0 : (BN * WU + 255) / 256;  // B slots per thread: 16-byte pieces of the row images
+  constexpr int NBA = NB > 0 ? NB : 1;
   constexpr int NSLOT = NA + NB;
+  static_assert(!WF || (NP == 2 && !STEM), "fragment-major weights: fp16 form of the plain per-tap kernel only");
   static_assert((BN == 128 || BN == 64) && (BM == 128 || (BM == 256 && BN == 64)) && TM == 2, "unsupported tile");
 
   __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
@@ -187,7 +194,9 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
   const long long img_elems = (long long)g.SH * g.SW * g.src_cstride;
   const int wchunks = g.wstride >> 4;
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(src + (long long)n0 * img_elems, ((long long)g.N - n0) * img_elems * 4);
-  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wsp), (long long)g.Cout * wchunks * WB);
+  const int J = (g.Cout + 31) >> 5;
+  const __amdgpu_buffer_rsrc_t rsB = make_rsrc(reinterpret_cast<const float*>(wsp), WF ? 2ll * wchunks * J * NP * 1024
+                                                                                          : (long long)g.Cout * wchunks * WB);
 
   if (tid < g.ntaps) {
     s_oy[tid] = g.offy[tid]; s_ox[tid] = g.offx[tid];
@@ -208,7 +217,7 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
     r_x[i] = tx * g.sx;
     r_base[i] = (((n - n0) * g.SH + ty * g.sy) * g.SW + tx * g.sx) * g.src_cstride;
   }
-  int b_off[NB], b_lds[NB];          // byte offset of this thread's 16-byte piece in the split weights (or -1), in LDS
+  int b_off[NBA], b_lds[NBA];        // byte offset of this thread's 16-byte piece in the split weights (or -1), in LDS
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
     const int e = tid + 256 * j;
@@ -226,7 +235,7 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
   dst += (long long)bi.y * slab_stride;
 
   float4 rs[NA];
-  u32x4 rb[NB];
+  u32x4 rb[NBA];
   float lim[NA];                     // prologue: +inf where the A slot holds a real element, 0 where it is padding
   int kc_held = 0;                   // first channel of the chunk the registers hold (prologue scale / shift lookup)
   // the next chunk to load, advanced incrementally (tap-major, channel chunks inside a tap)
@@ -252,6 +261,24 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
     } else {
       const int j = sl - NA;
       rb[j] = __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[j] >= 0 ? (unsigned)(b_off[j] + c_wo) : OOB, 0, 0);
+    }
+  };
+  // WF: the weight fragments of the chunk computed NEXT, per wave (double-buffered by chunk parity like the accumulators)
+  bf16x8 fbq[2][TN][NP];
+  int w_t = (cbeg < nch ? cbeg : 0) / kch, w_k = (cbeg < nch ? cbeg : 0) - w_t * kch;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const int jt0 = (co0 >> 5) + wn * TN;
+  auto load_wf = [&](auto S) {
+    constexpr int s_ = decltype(S)::value;
+    if constexpr (WF) {
+      const int c = (g.wofs[w_t] >> 4) + w_k;
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+          fbq[s_][b][p] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(
+              rsB, (unsigned)(((c * J + jt0 + b) * NP + p) * 1024) + lane16, 0, 0));
+      if (w_t * kch + w_k + 1 < cend) { w_k += 1; if (w_k == kch) { w_k = 0; w_t += 1; } }
     }
   };
   float4 p_sc = zero4(), p_sh = zero4();
@@ -300,6 +327,7 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[s_][a][b][r] = 0.f;
 
+  load_wf(std::integral_constant<int, 0>{});      // WF: chunk cbeg
   // Software pipeline as in conv_gather_kernel: registers hold chunk i+1 while chunk i is computed; each slot is written
   // to the other LDS buffer and re-loaded with chunk i+2 between groups of MFMAs; one barrier per chunk.
   next_chunk();
@@ -345,8 +373,12 @@ void conv_gather_x3_body(const float* __restrict__ src, const unsigned char* __r
 #pragma unroll
       for (int a = 0; a < TM; ++a) fa[a][p] = *reinterpret_cast<const bf16x8*>(Ab + a * 32 * ROWB + p * 32);
 #pragma unroll
-      for (int b = 0; b < TN; ++b) fb[b][p] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * ROWB + p * 32);
+      for (int b = 0; b < TN; ++b) {
+        if constexpr (WF) fb[b][p] = fbq[par][b][p];
+        else fb[b][p] = *reinterpret_cast<const bf16x8*>(Bb + b * 32 * ROWB + p * 32);
+      }
     }
+    load_wf(std::integral_constant<int, 1 - par>{});                   // WF: the next chunk's weight fragments
     mfma_range(0, G0);
     if (has_pro) load_pro(kc_held);
     next_chunk();
@@ -2082,25 +2114,25 @@ __device__ __forceinline__ int multi_level(const MP& P) {
 #define DCS_BLK BlkId{(int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y}
 #define DCS_BLK2 BlkId{(int)blockIdx.x, (int)gridDim.x, (int)blockIdx.y, (int)gridDim.y}
 
-template <int BN, int BM = 128, bool STEM = false, int NP = 3>
+template <int BN, int BM = 128, bool STEM = false, int NP = 3, bool WF = false>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_x3_kernel(const float* __restrict__ src, const unsigned char* __restrict__ wsp,
                            const float* __restrict__ bias, float* __restrict__ dst, const DcsConvGeom g,
                            const int accumulate, const int ntiles, float* __restrict__ stats, const int cps,
                            const long long slab_stride, const BnBwdEpi bnb, const float* __restrict__ pro,
                            const unsigned* __restrict__ src_max) {
-  conv_gather_x3_body<BN, BM, STEM, NP>(src, wsp, bias, dst, g, accumulate, ntiles, stats, cps, slab_stride, bnb, pro, DCS_BLK,
-                                        src_max);
+  conv_gather_x3_body<BN, BM, STEM, NP, WF>(src, wsp, bias, dst, g, accumulate, ntiles, stats, cps, slab_stride, bnb, pro, DCS_BLK,
+                                            src_max);
 }
-template <int BN, int BM = 128, bool STEM = false, int NP = 3>
+template <int BN, int BM = 128, bool STEM = false, int NP = 3, bool WF = false>
 __global__ __launch_bounds__(256, 2)
 void conv_gather_x3_multi_kernel(const GatherMulti P) {
   const int lv = multi_level(P);
   const GatherSub& s = P.s[lv];
   const int rel = (int)blockIdx.x - s.blk0;
   if (rel >= s.nblk) return;
-  conv_gather_x3_body<BN, BM, STEM, NP>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.cps, s.slab_stride,
-                                        s.bnb, s.pro, BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.src_max);
+  conv_gather_x3_body<BN, BM, STEM, NP, WF>(s.src, s.w, s.bias, s.dst, P.g[lv], s.accumulate, s.ntiles, s.stats, s.cps,
+                                            s.slab_stride, s.bnb, s.pro, BlkId{rel % s.nbx, s.nbx, rel / s.nbx}, s.src_max);
 }
 
 template <int BN, int TH, int NP = 3>
@@ -2244,7 +2276,8 @@ namespace {
 
 // ---- launch plans: validation + kernel choice of one (sub-)launch, shared by the single and the multi entries -----------
 enum GatherKid { GK_X3W_64, GK_X3W_128, GK_X2H_64, GK_X2H_128, GK_HALO_64, GK_HALO_128, GK_STEM_256, GK_STEM_128, GK_128, GK_64_256, GK_64, GK_STEM7,
-                 GK_H2 = 32 /* flag: the per-tap kernels in their fp16 two-piece form */ };
+                 GK_H2 = 32 /* flag: the per-tap kernels in their fp16 two-piece form */,
+                 GK_WF = 64 /* flag: ... with the weight fragments straight from global memory (DCS_ACC_WFRAG) */ };
 struct GatherPlan { int kid; DcsConvGeom g; GatherSub s; unsigned nbx, nby; };
 
 int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
@@ -2271,8 +2304,8 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
       return DCS_E_UNSUPPORTED;
   }
   const BnBwdEpi bnb{a.bn_y, a.bn_mask, a.bn, a.relu};
-  const bool accum = (a.accumulate & 1) != 0, h2 = (a.accumulate & DCS_ACC_FP16X2) != 0;
-  DCS_CHECK_ARG((a.accumulate & ~(1 | DCS_ACC_FP16X2)) == 0);
+  const bool accum = (a.accumulate & 1) != 0, h2 = (a.accumulate & DCS_ACC_FP16X2) != 0, wf = (a.accumulate & DCS_ACC_WFRAG) != 0;
+  DCS_CHECK_ARG((a.accumulate & ~(1 | DCS_ACC_FP16X2 | DCS_ACC_WFRAG)) == 0 && (!wf || (h2 && !geom->stem)));
   DCS_CHECK_ARG(!(a.stats && accum && !bnb.y));
   DCS_CHECK_ARG(!a.pro || (geom->K <= DCS_PRO_MAXK && dcs_aligned16(a.pro)));
   DCS_CHECK_ARG(!bnb.y || (a.stats && bnb.bn && nsplit == 1 && (geom->Cout & 3) == 0 && geom->dst_cstride == geom->Cout &&
@@ -2314,6 +2347,7 @@ int plan_gather_x3(const DcsGatherLaunch& a, GatherPlan& P) {
   else P.kid = bm256 ? GK_64_256 : GK_64;
   if (P.kid != GK_128 && P.kid != GK_64) DCS_CHECK_ARG(nsplit == 1);
   if (h2) P.kid |= GK_H2;
+  if (wf) P.kid |= GK_WF;
   return DCS_OK;
 }
 
@@ -2406,7 +2440,10 @@ int launch_gather_one(const GatherPlan& P, hipStream_t s) {
       break;
 #define DCS_TAP(BN_, BM_, ST_)                                                                                                  \
   do {                                                                                                                        \
-    if (P.kid & GK_H2)                                                                                                        \
+    if ((P.kid & GK_WF) && !ST_)                                                                                              \
+      hipLaunchKernelGGL((conv_gather_x3_kernel<BN_, BM_, false, 2, true>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps,     \
+                         P.s.slab_stride, P.s.bnb, P.s.pro, P.s.src_max);                                                    \
+    else if (P.kid & GK_H2)                                                                                                   \
       hipLaunchKernelGGL((conv_gather_x3_kernel<BN_, BM_, ST_, 2>), grid, blk, 0, s, DCS_GATHER_ARGS(P), P.s.cps,             \
                          P.s.slab_stride, P.s.bnb, P.s.pro, P.s.src_max);                                                    \
     else                                                                                                                      \
@@ -2415,8 +2452,8 @@ int launch_gather_one(const GatherPlan& P, hipStream_t s) {
   } while (0)
     case GK_STEM_256: case GK_STEM_256 | GK_H2: DCS_TAP(64, 256, true); break;
     case GK_STEM_128: case GK_STEM_128 | GK_H2: DCS_TAP(64, 128, true); break;
-    case GK_128: case GK_128 | GK_H2: DCS_TAP(128, 128, false); break;
-    case GK_64_256: case GK_64_256 | GK_H2: DCS_TAP(64, 256, false); break;
+    case GK_128: case GK_128 | GK_H2: case GK_128 | GK_H2 | GK_WF: DCS_TAP(128, 128, false); break;
+    case GK_64_256: case GK_64_256 | GK_H2: case GK_64_256 | GK_H2 | GK_WF: DCS_TAP(64, 256, false); break;
     default: DCS_TAP(64, 128, false);
 #undef DCS_TAP
   }
@@ -2473,6 +2510,9 @@ int launch_gather_multi(const GatherPlan* const* plans, int n, hipStream_t s) {
     case GK_128 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<128, 128, false, 2>), grid, blk, 0, s, mp); break;
     case GK_64_256 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, false, 2>), grid, blk, 0, s, mp); break;
     case GK_64 | GK_H2: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, false, 2>), grid, blk, 0, s, mp); break;
+    case GK_128 | GK_H2 | GK_WF: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<128, 128, false, 2, true>), grid, blk, 0, s, mp); break;
+    case GK_64_256 | GK_H2 | GK_WF: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 256, false, 2, true>), grid, blk, 0, s, mp); break;
+    case GK_64 | GK_H2 | GK_WF: hipLaunchKernelGGL((conv_gather_x3_multi_kernel<64, 128, false, 2, true>), grid, blk, 0, s, mp); break;
     default: return DCS_E_ARG;
   }
   return hipGetLastError() == hipSuccess ? DCS_OK : DCS_E_LAUNCH;

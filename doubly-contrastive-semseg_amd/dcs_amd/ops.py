@@ -447,7 +447,8 @@ def split_weight_frag(wk):
     return out
 
 
-ACC_FP16X2 = 16          # DCS_ACC_FP16X2 (include/dcs_hip.h)
+ACC_FP16X2 = 16
+ACC_WFRAG = 32         # DCS_ACC_WFRAG: dcs_conv_gather_x3 reads a fragment-major weight image          # DCS_ACC_FP16X2 (include/dcs_hip.h)
 
 
 def split_weight_h2(wk):
@@ -556,8 +557,15 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
     elif x3_ok(g):
         smax = None if fwd else getattr(src, "_dcs_max", None)
         if ((fwd and _x2h_forward[0]) or smax is not None) and x2h_on():
-            _call("dcs_conv_gather_x3", _p(src), _p(split_weight_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
-                  _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _p(smax), _stream())
+            if not g.stem and os.environ.get("DCS_TAP_WFRAG", "1") != "0":
+                # weight fragments straight from global memory (fragment-major image): the LDS-staged fp16 form is
+                # LDS-bandwidth bound
+                _call("dcs_conv_gather_x3", _p(src), _p(split_weight_frag_h2(wgt)), _p(bias), _p(dst), g,
+                      accumulate | ACC_FP16X2 | ACC_WFRAG, _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns,
+                      slab_n, _p(smax), _stream())
+            else:
+                _call("dcs_conv_gather_x3", _p(src), _p(split_weight_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
+                      _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _p(smax), _stream())
         else:
             _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
                   _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, None, _stream())

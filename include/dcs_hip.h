@@ -145,6 +145,10 @@ int dcs_conv_gather_x3(const float* src, const void* wsplit, const float* bias, 
  * / src_max, and an output map of whole 8 x 32-pixel tiles the same entry runs the stem forward with its input patch
  * resident in LDS (stem7_h2_kernel); other stem launches: DCS_E_UNSUPPORTED (use dcs_conv_gather_x3). */
 #define DCS_ACC_FP16X2 16
+/* with DCS_ACC_FP16X2 on dcs_conv_gather_x3 (not the stem): wsplit is the FRAGMENT-major image of dcs_split_weight_frag_h2 and
+ * the kernel reads its weight fragments straight from global memory instead of staging them through LDS (round 3: the
+ * LDS-staged fp16 form was LDS-bandwidth bound) -- same products in the same order, bitwise the same results. */
+#define DCS_ACC_WFRAG 32
 int dcs_split_weight_frag(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_split_weight_frag_h2(const float* w, void* out, int64_t rows, int wstride, void* stream);
 int dcs_conv3x3_x3w(const float* src, const void* wfrag, const float* bias, float* dst, const DcsConvGeom* geom,

@@ -142,6 +142,33 @@ def test_stem_conv_and_wgrad(ops, N, H, W):
     close(got, E.unpack_stem_weight(dref, w), 5e-5, "stem wgrad")
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,dil", [
+    (2, 20, 36, 256, 128, 1, 1, 1), (4, 16, 24, 64, 128, 3, 2, 1), (2, 33, 29, 128, 80, 3, 1, 1), (2, 24, 40, 128, 64, 3, 1, 2),
+    (8, 64, 128, 64, 64, 1, 1, 1), (1, 8, 8, 512, 512, 3, 1, 1),
+])
+def test_per_tap_kernel_with_weight_fragments_from_global_is_bitwise_the_lds_staged_one(ops, monkeypatch, N, H, W, Cin, Cout,
+                                                                                       k, s, dil):
+    """conv_gather_x3_kernel<.., 2, WF = true> (weight fragments straight from global memory, DCS_ACC_WFRAG) against the
+    LDS-staged fp16 kernel: 1x1, stride 2 (forward and the parity classes of its data gradient), ragged widths / channel
+    counts, dilation, 256-pixel tiles, K splits of a tiny map -- the same products in the same order."""
+    ops.new_step(True)
+    pad = dil * (k // 2)
+    x = rnd(N, H, W, Cin, seed=221).to(DEV)
+    w = cl(rnd(Cout, Cin, k, k, seed=222, scale=0.05).to(DEV))
+    OH, OW = ops.out_size_d(H, k, s, pad, dil), ops.out_size_d(W, k, s, pad, dil)
+    dy = rnd(N, OH, OW, Cout, seed=223).to(DEV) * 1e-3
+    ops.tag_max(dy)
+    wpk = ops.pack_dgrad_weight(w)
+    outs = {}
+    for wf in ("1", "0"):
+        monkeypatch.setenv("DCS_TAP_WFRAG", wf)
+        y, st = ops.conv_fwd(x, w, s, pad, want_stats=True, dil=dil)
+        gx = ops.conv_dgrad(dy, wpk, (H, W), s, pad, dil=dil)
+        outs[wf] = (y, st, gx)
+    for a, b in zip(outs["1"], outs["0"]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(8, 64, 128, 64, 64), (16, 32, 64, 128, 128), (8, 32, 64, 512, 256), (8, 64, 128, 96, 64)])
 def test_double_buffered_halo_kernel_is_bitwise_the_single_buffered_one(ops, libopt, N, H, W, Cin, Cout):
     """conv3x3_x3w_db_kernel (halo of the next 16 channels written into a second LDS buffer behind the MFMAs, one barrier per
