@@ -192,7 +192,8 @@ __global__ void bn_ema_again_kernel(const float* __restrict__ bn, float* __restr
 
 __global__ __launch_bounds__(256)
 void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bn, const float* __restrict__ r,
-                   const float* __restrict__ bn2, float* __restrict__ z, long long n4, int C, int relu, int nt) {
+                   const float* __restrict__ bn2, float* __restrict__ z, long long n4, int C, int relu, int nt,
+                   unsigned char* __restrict__ mask8) {
   const int C4 = C >> 2;
   // C/4 divides the block size for every BatchNorm width of the networks (64..2048 channels): a thread then keeps ONE
   // channel group for the whole grid-stride loop and its per-channel constants live in registers (7 fewer L1 loads per
@@ -218,6 +219,9 @@ void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bn, co
     }
     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
     st4s(z + i * 4, o, nt);
+    // the ReLU mask of the four values as one byte: the backward (dcs_bn_bwd_apply, the BatchNorm-backward epilogue of the
+    // data gradient) then reads 1 byte instead of 16 of z
+    if (mask8) mask8[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
   }
 }
 
@@ -227,7 +231,8 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
                          const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
                          float* __restrict__ dy, float* __restrict__ gm_out, float* __restrict__ dgamma,
                          float* __restrict__ dbeta, long long rows, int C, int relu, int acc_dy, int acc_gm,
-                         int acc_param, int training, unsigned* __restrict__ dy_maxabs) {
+                         int acc_param, int training, unsigned* __restrict__ dy_maxabs,
+                         const unsigned char* __restrict__ mask8) {
   const int C4 = C >> 2;
   float mx = 0.f;
   const long long n4 = rows * C4;
@@ -255,7 +260,10 @@ void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ 
     if (!hoist) tab((int)(i % C4) * 4);
     float4 v = ldx4<NT>(g + i * 4);
     const float4 yy = ldx4<NT>(y + i * 4);
-    if (masksrc) {
+    if (mask8) {                                          // one byte per four values (dcs_bn_act's mask8)
+      const unsigned m = mask8[i];
+      v.x = (m & 1u) ? v.x : 0.f; v.y = (m & 2u) ? v.y : 0.f; v.z = (m & 4u) ? v.z : 0.f; v.w = (m & 8u) ? v.w : 0.f;
+    } else if (masksrc) {
       const float4 ms = ldx4<NT>(masksrc + i * 4);
       v.x = ms.x > 0.f ? v.x : 0.f; v.y = ms.y > 0.f ? v.y : 0.f; v.z = ms.z > 0.f ? v.z : 0.f; v.w = ms.w > 0.f ? v.w : 0.f;
     } else if (relu) {
@@ -465,19 +473,19 @@ extern "C" int dcs_bn_ema_again(const float* bn, float* running_mean, float* run
 }
 
 extern "C" int dcs_bn_act(const float* y, const float* bn, const float* r, const float* bn2, float* z, int64_t rows,
-                          int C, int relu, void* stream) {
+                          int C, int relu, uint8_t* mask8, void* stream) {
   DCS_CHECK_ARG(y && bn && z && rows > 0 && C > 0 && (C & 3) == 0 && dcs_aligned16(y) && dcs_aligned16(z));
   const long long n4 = (long long)rows * (C / 4);
   hipLaunchKernelGGL(bn_act_kernel, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), y, bn, r, bn2, z, n4, C, relu,
-                     dcs_streams(n4 * 16) ? 1 : 0);
+                     dcs_streams(n4 * 16) ? 1 : 0, mask8);
   DCS_LAUNCH_RET();
 }
 
 extern "C" int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
                                 const float* gamma, const float* sums, float* dy, float* gm_out, float* dgamma,
                                 float* dbeta, int64_t rows, int C, int relu, int acc_dy, int acc_gm, int acc_param,
-                                int training, uint32_t* dy_maxabs, void* stream) {
-  DCS_CHECK_ARG(g && y && bn && rows > 0 && C > 0 && (C & 3) == 0);
+                                int training, uint32_t* dy_maxabs, const uint8_t* mask8, void* stream) {
+  DCS_CHECK_ARG(g && y && bn && rows > 0 && C > 0 && (C & 3) == 0 && !(mask8 && masksrc));
   DCS_CHECK_ARG(!dy_maxabs || dy);
   DCS_CHECK_ARG(!dy || (gamma && sums));
   DCS_CHECK_ARG((dgamma == nullptr) == (dbeta == nullptr) && (!dgamma || sums));
@@ -485,10 +493,10 @@ extern "C" int dcs_bn_bwd_apply(const float* g, const float* y, const float* mas
   const bool nt = dcs_streams(n4 * 16);               // >= 256 MiB per tensor: nothing to keep in the caches
   if (nt)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<true>, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
-                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training, dy_maxabs);
+                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training, dy_maxabs, mask8);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<false>, dim3(grid_for(n4)), dim3(256), 0, dcs_stream(stream), g, y, masksrc, bn, gamma,
-                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training, dy_maxabs);
+                       sums, dy, gm_out, dgamma, dbeta, (long long)rows, C, relu, acc_dy, acc_gm, acc_param, training, dy_maxabs, mask8);
   DCS_LAUNCH_RET();
 }
 

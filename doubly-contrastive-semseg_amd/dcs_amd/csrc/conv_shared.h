@@ -38,6 +38,8 @@ __device__ __forceinline__ float4 pro_apply(const float4 v, const float4 sc, con
 // BatchNorm-backward sums in a data-gradient epilogue (see conv_epilogue): y = the input of the BatchNorm whose
 // output gradient this launch produces (same [M][dst_cstride] layout as dst), mask = the tensor whose sign is the ReLU
 // mask (nullable), bn = [scale, shift, mean, invstd] x C record, relu = derive the mask from y*scale+shift.
+// relu: 0 = ReLU mask from `mask > 0` (or none), 1 = from the recomputed BatchNorm output, 2 = `mask` points to BYTES, the four
+// mask bits of every float4 of the tensor (dcs_bn_act's mask8: 1 byte read instead of 16)
 struct BnBwdEpi { const float* y; const float* mask; const float* bn; int relu; };
 
 // Epilogue shared by the convolution kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
@@ -129,7 +131,10 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
         if (acc_dst) pre_o[p] = ld4s(dst + ro + colv, nt);
         if (do_bnb) {
           pre_y[p] = ld4s(bnb.y + ro + colv, nt);
-          if (bnb.mask) pre_m[p] = ld4s(bnb.mask + ro + colv, nt);
+          if (bnb.mask) {
+            if (bnb.relu == 2) pre_m[p].x = __uint_as_float((unsigned)reinterpret_cast<const unsigned char*>(bnb.mask)[(ro + colv) >> 2]);
+            else pre_m[p] = ld4s(bnb.mask + ro + colv, nt);
+          }
         }
       }
     }
@@ -146,7 +151,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
         if (do_bnb) {
           const float4 yy = PRE ? pre_y[PRE ? p : 0] : ld4s(bnb.y + ro + colv, nt);
           float4 gm = v;
-          if (bnb.mask) {
+          if (bnb.mask && bnb.relu == 2) {
+            const unsigned m = PRE ? __float_as_uint(pre_m[PRE ? p : 0].x)
+                                   : (unsigned)reinterpret_cast<const unsigned char*>(bnb.mask)[(ro + colv) >> 2];
+            gm.x = (m & 1u) ? gm.x : 0.f; gm.y = (m & 2u) ? gm.y : 0.f; gm.z = (m & 4u) ? gm.z : 0.f; gm.w = (m & 8u) ? gm.w : 0.f;
+          } else if (bnb.mask) {
             const float4 ms = PRE ? pre_m[PRE ? p : 0] : ld4s(bnb.mask + ro + colv, nt);
             gm.x = ms.x > 0.f ? gm.x : 0.f; gm.y = ms.y > 0.f ? gm.y : 0.f; gm.z = ms.z > 0.f ? gm.z : 0.f; gm.w = ms.w > 0.f ? gm.w : 0.f;
           } else if (bnb.relu) {

@@ -76,8 +76,8 @@ SIGNATURES = {
     "dcs_bn_finalize": [_P, _P, _P, _P, _P, _P, _I, _D, _F, _F, _I, _I, _P],
     "dcs_bn_ema_again": [_P, _P, _P, _I, _D, _F, _F, _P],
     "dcs_maxabs": [_P, _L, _P, _P],
-    "dcs_bn_act": [_P, _P, _P, _P, _P, _L, _I, _I, _P],
-    "dcs_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P],
+    "dcs_bn_act": [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P],
+    "dcs_bn_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _I, _P, _P, _P],
     "dcs_normalize_pyramid": [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "dcs_bn_relu_maxpool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dcs_maxpool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],

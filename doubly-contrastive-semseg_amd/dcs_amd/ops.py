@@ -542,6 +542,10 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
     (activations x weights: operands of known magnitude -> the fp16 two-piece kernel where it applies); a data gradient
     takes that kernel when its source carries the device word with its maximum (bn_bwd's dy: ``_dcs_max``)."""
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
+    m8 = getattr(mb, "_mask8", None) if (mb is not None and mask8_on()) else None
+    if m8 is not None:                       # the byte mask dcs_bn_act left beside the tensor: relu = 2 (include/dcs_hip.h)
+        mb, relu = m8, 2
+    relu = int(relu)
     if (ns == 1 and g.stem and fwd and bias is None and pro is None and bnb is None and x3_ok(g) and stem7_ok(g) and
             _x2h_forward[0] and x2h_on()):
         _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag_h2(wgt)), None, _p(dst), g, accumulate | ACC_FP16X2,
@@ -550,10 +554,10 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
         smax = None if fwd else getattr(src, "_dcs_max", None)
         if ((fwd and _x2h_forward[0]) or smax is not None) and x2h_on():
             _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
-                  _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, _p(smax), _stream())
+                  _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), relu, _p(smax), _stream())
         else:
             _call("dcs_conv3x3_x3w", _p(src), _p(split_weight_frag(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
-                  _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, None, _stream())
+                  _p(pro), _p(yb), _p(mb), _p(bnr), relu, None, _stream())
     elif x3_ok(g):
         smax = None if fwd else getattr(src, "_dcs_max", None)
         if ((fwd and _x2h_forward[0]) or smax is not None) and x2h_on():
@@ -561,18 +565,18 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
                 # weight fragments straight from global memory (fragment-major image): the LDS-staged fp16 form is
                 # LDS-bandwidth bound
                 _call("dcs_conv_gather_x3", _p(src), _p(split_weight_frag_h2(wgt)), _p(bias), _p(dst), g,
-                      accumulate | ACC_FP16X2 | ACC_WFRAG, _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns,
+                      accumulate | ACC_FP16X2 | ACC_WFRAG, _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), relu, ns,
                       slab_n, _p(smax), _stream())
             else:
                 _call("dcs_conv_gather_x3", _p(src), _p(split_weight_h2(wgt)), _p(bias), _p(dst), g, accumulate | ACC_FP16X2,
-                      _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, _p(smax), _stream())
+                      _p(stats), _p(pro), _p(yb), _p(mb), _p(bnr), relu, ns, slab_n, _p(smax), _stream())
         else:
             _call("dcs_conv_gather_x3", _p(src), _p(split_weight(wgt)), _p(bias), _p(dst), g, accumulate, _p(stats),
-                  _p(pro), _p(yb), _p(mb), _p(bnr), 1 if relu else 0, ns, slab_n, None, _stream())
+                  _p(pro), _p(yb), _p(mb), _p(bnr), relu, ns, slab_n, None, _stream())
     elif bnb is not None:
         assert pro is None and ns == 1
         _call("dcs_conv_gather_bnbwd", _p(src), _p(wgt), _p(dst), C.byref(g), accumulate, _p(yb), _p(mb), _p(bnr),
-              1 if relu else 0, _p(stats), _stream())
+              relu, _p(stats), _stream())
     elif pro is not None:
         _call("dcs_conv_gather_pro", _p(src), _p(wgt), _p(bias), _p(dst), C.byref(g), accumulate, _p(stats), _p(pro), ns,
               slab_n, _stream())
@@ -891,8 +895,21 @@ def bn_act(y, bn, r=None, bn2=None, relu=True):
     _req(y)
     z = torch.empty_like(y)
     Cc = y.shape[-1]
-    _call("dcs_bn_act", _p(y), _p(bn), _p(r), _p(bn2), _p(z), y.numel() // Cc, Cc, 1 if relu else 0, _stream())
+    # a residual block's output in a training forward: its ReLU mask as one byte per float4 beside it -- the backward reads
+    # the mask twice (bn_bwd of the block's last BatchNorm, the BatchNorm-backward epilogue of the data gradient that
+    # produces its incoming gradient): 1 byte instead of 16 of z each time
+    m8 = None
+    if relu and r is not None and y.is_cuda and _x2h_forward[0] and mask8_on():
+        m8 = torch.empty((y.numel() // 4,), device=y.device, dtype=torch.uint8)
+    _call("dcs_bn_act", _p(y), _p(bn), _p(r), _p(bn2), _p(z), y.numel() // Cc, Cc, 1 if relu else 0, _p(m8), _stream())
+    if m8 is not None:
+        z._mask8 = m8
     return z
+
+
+def mask8_on():
+    """Byte ReLU masks beside residual-block outputs (DCS_MASK8=0: the backward reads the float tensor)."""
+    return os.environ.get("DCS_MASK8", "1") != "0"
 
 
 def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=False, dy_out=None, acc_dy=False,
@@ -918,9 +935,10 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
         # the maximum of |dy| rides along (one integer atomicMax per wave): the convolutions that consume dy -- data and
         # weight gradient -- scale it by an exact power of two into fp16 range (csrc/conv_split.hip, two fp16 pieces)
         smax = _max_slot(y.device)
-    _call("dcs_bn_bwd_apply", _p(g), _p(y), _p(masksrc), _p(bn), _p(gamma), _p(sums), _p(dy), _p(gm), _p(dgamma),
-          _p(dbeta), rows, Cc, 1 if relu else 0, 1 if (acc_dy and dy_out is not None) else 0, 0,
-          1 if acc_param else 0, 1 if training else 0, _p(smax), _stream())
+    m8 = getattr(masksrc, "_mask8", None) if (masksrc is not None and mask8_on()) else None
+    _call("dcs_bn_bwd_apply", _p(g), _p(y), None if m8 is not None else _p(masksrc), _p(bn), _p(gamma), _p(sums), _p(dy),
+          _p(gm), _p(dgamma), _p(dbeta), rows, Cc, 1 if relu else 0, 1 if (acc_dy and dy_out is not None) else 0, 0,
+          1 if acc_param else 0, 1 if training else 0, _p(smax), _p(m8), _stream())
     if smax is not None:
         dy._dcs_max = smax
     return dy, gm

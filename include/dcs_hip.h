@@ -78,7 +78,7 @@ int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float
  * [ceil(M/DCS_CONV_BM)][2][Cout] receives per row tile sum(gm) and sum(gm * xhat), gm = (final dst value, after the
  * optional accumulate) * ReLU mask, xhat = (bn_y - mean) * invstd -- the sums dcs_colsum_partial(mode 1) would take in a
  * pass of its own.  bn_y (and bn_mask, nullable: mask = bn_mask > 0; else relu ? bn_y*scale+shift > 0 : 1) have dst's
- * layout; dst must be dense (dst_cstride == Cout, Cout % 4 == 0).  Stride-2 data gradients are several launches (one
+ * layout; relu = 2: bn_mask points to the BYTE mask dcs_bn_act wrote for that tensor (four bits per float4; 1/16 of the bytes); dst must be dense (dst_cstride == Cout, Cout % 4 == 0).  Stride-2 data gradients are several launches (one
  * per input parity class), each with its own rows of part; dcs_colsum_final sums them all. */
 int dcs_conv_gather_bnbwd(const float* src, const float* wgt, float* dst, const DcsConvGeom* geom, int accumulate,
                           const float* bn_y, const float* bn_mask, const float* bn, int relu, float* part, void* stream);
@@ -234,9 +234,12 @@ int dcs_bn_finalize(const float* sums, const float* gamma, const float* beta, fl
 int dcs_bn_ema_again(const float* bn, float* running_mean, float* running_var, int C, double count,
                      float eps, float momentum, void* stream);
 
-/* z = act(y*scale+shift [+ r | + r*scale2+shift2]); act = relu if relu.  bn2 null -> identity r. */
+/* z = act(y*scale+shift [+ r | + r*scale2+shift2]); act = relu if relu.  bn2 null -> identity r.
+ * mask8 (nullable, rows * C / 4 bytes): byte i receives the four bits (z > 0) of float4 i -- the ReLU mask of a residual
+ * block's output (resnet_pyramid.py:38-60, `relu(out + residual)`), which dcs_bn_bwd_apply (mask8) and the
+ * BatchNorm-backward epilogue of a data gradient (relu = 2) then read instead of the 16 bytes of z. */
 int dcs_bn_act(const float* y, const float* bn, const float* r, const float* bn2, float* z,
-               int64_t rows, int C, int relu, void* stream);
+               int64_t rows, int C, int relu, uint8_t* mask8, void* stream);
 /* BN backward apply: gm = g*mask; dy (+)= gamma*invstd*(gm - s0/cnt - xhat*s1/cnt);
  * optional gm_out (+)= gm.  sums = [2][C] from dcs_colsum_* mode 1.  dgamma/dbeta (+)= s1/s0.
  * training = 0 (eval-mode BN, running statistics): dy = gamma*invstd*gm.
@@ -249,7 +252,8 @@ int dcs_maxabs(const float* x, int64_t n, uint32_t* out, void* stream);
 int dcs_bn_bwd_apply(const float* g, const float* y, const float* masksrc, const float* bn,
                      const float* gamma, const float* sums, float* dy, float* gm_out,
                      float* dgamma, float* dbeta, int64_t rows, int C, int relu, int acc_dy,
-                     int acc_gm, int acc_param, int training, uint32_t* dy_maxabs, void* stream);
+                     int acc_gm, int acc_param, int training, uint32_t* dy_maxabs, const uint8_t* mask8,
+                     void* stream);   /* mask8 (nullable; then masksrc must be null): the byte mask dcs_bn_act wrote */
 
 /* ---- pyramid / pooling / resize -------------------------------------------------------------*/
 /* resnet_pyramid.py:296-314: (x-mean)/std then bicubic 1/2 and 1/4 (A=-0.75, no antialias).

@@ -37,7 +37,7 @@ def test_argument_errors_are_reported_not_crashed():
     from dcs_amd import lib
     l = lib.load()
     assert l.dcs_reduce_slab(None, None, 0, 0, 0, 0, 0, None) == -1
-    assert l.dcs_bn_act(None, None, None, None, None, 0, 0, 0, None) == -1
+    assert l.dcs_bn_act(None, None, None, None, None, 0, 0, 0, None, None) == -1
     g = lib.DcsConvGeom()
     assert l.dcs_conv_gather(None, None, None, None, g, 0, None, None) == -1
     with pytest.raises(RuntimeError, match="DCS_E_ARG"):

@@ -142,6 +142,34 @@ def test_stem_conv_and_wgrad(ops, N, H, W):
     close(got, E.unpack_stem_weight(dref, w), 5e-5, "stem wgrad")
 
 
+@pytest.mark.parametrize("N,H,W,Cc", [(2, 24, 40, 64), (4, 64, 128, 128), (3, 17, 23, 256)])
+def test_byte_relu_mask_beside_a_residual_output(ops, monkeypatch, N, H, W, Cc):
+    """dcs_bn_act's mask8 (four bits per float4 of a residual block's output) and its two readers -- dcs_bn_bwd_apply and
+    the BatchNorm-backward epilogue of a data gradient (relu = 2): every result bitwise the float-mask route's."""
+    ops.new_step(True)
+    y, r = rnd(N, H, W, Cc, seed=231).to(DEV), rnd(N, H, W, Cc, seed=232).to(DEV)
+    gam, bet = (rnd(Cc, seed=233) * 0.1 + 1).to(DEV), (rnd(Cc, seed=234) * 0.1).to(DEV)
+    bn = ops.bn_finalize(ops.colsum(y.reshape(-1, Cc), moments=True), gam, bet, torch.zeros(Cc, device=DEV),
+                         torch.ones(Cc, device=DEV), N * H * W, True)
+    out = ops.bn_act(y, bn, r=r, relu=True)
+    m8 = out._mask8
+    bits = (out.reshape(-1, 4) > 0).to(torch.uint8)
+    assert torch.equal(m8, bits[:, 0] | (bits[:, 1] << 1) | (bits[:, 2] << 2) | (bits[:, 3] << 3))
+    g = rnd(N, H, W, Cc, seed=235).to(DEV)
+    w = cl(rnd(Cc, Cc, 3, 3, seed=236, scale=0.05).to(DEV))
+    dy = rnd(N, H, W, Cc, seed=237).to(DEV) * 1e-2
+    res = {}
+    for on in ("1", "0"):
+        monkeypatch.setenv("DCS_MASK8", on)
+        dyo, _ = ops.bn_bwd(g, y, bn, gam, masksrc=out)
+        dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+        gx, sums = ops.conv_dgrad(dy, ops.pack_dgrad_weight(w), (H, W), 1, 1, bnb=(y, out, bn, False))
+        dy2, _ = ops.bn_bwd(gx, y, bn, gam, masksrc=out, dgamma=dg, dbeta=db, sums=sums)
+        res[on] = (dyo, gx, sums, dy2, dg, db)
+    for a, b in zip(res["1"], res["0"]):
+        assert (a is None and b is None) or torch.equal(a, b)      # (a split-K launch of a tiny map carries no sums)
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,k,s,dil", [
     (2, 20, 36, 256, 128, 1, 1, 1), (4, 16, 24, 64, 128, 3, 2, 1), (2, 33, 29, 128, 80, 3, 1, 1), (2, 24, 40, 128, 64, 3, 1, 2),
     (8, 64, 128, 64, 64, 1, 1, 1), (1, 8, 8, 512, 512, 3, 1, 1),

@@ -20,9 +20,13 @@ HBM_PEAK_TBS = 8.0
 SPARSE = {"gather_rows", "scatter_add_rows", "gather_rows_bilinear", "scatter_rows_bilinear"}
 
 
-def tensors_of(obj, acc):
+def tensors_of(obj, acc, mask=False):
     if torch.is_tensor(obj):
         if obj.is_cuda:
+            m8 = getattr(obj, "_mask8", None) if mask else None
+            if m8 is not None and os.environ.get("DCS_MASK8", "1") != "0":      # read through its byte mask (ops.bn_bwd masksrc)
+                acc[m8.data_ptr()] = m8.numel()
+                return
             acc[obj.data_ptr()] = max(acc.get(obj.data_ptr(), 0), obj.numel() * obj.element_size())
     elif isinstance(obj, (list, tuple)):
         for o in obj:
@@ -59,7 +63,9 @@ class OpProfiler:
             if not self.enabled or self._depth:          # an op called by another op belongs to the outer one
                 return fn(*a, **k)
             acc = {}
-            tensors_of(a, acc); tensors_of(k, acc)
+            tensors_of(a, acc)
+            tensors_of({kk: v for kk, v in k.items() if kk != "masksrc"}, acc)
+            tensors_of(k.get("masksrc"), acc, mask=True)    # a ReLU-mask source is read as 1 byte per float4 when it has one
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             self._depth += 1
