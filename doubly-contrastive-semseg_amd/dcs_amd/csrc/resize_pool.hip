@@ -209,6 +209,69 @@ void bn_pool_bwd_partial_kernel(const float* __restrict__ g, const uint8_t* __re
   }
 }
 
+// The same two sums from the POOLED tensors alone (round 3).  Every pooled gradient lands on exactly one un-pooled position
+// (its window's argmax), the ReLU there is open exactly when the pooled output z is positive, and there z = scale * y +
+// shift, so y -- and with it xhat = (y - mean) * invstd -- follows from z: sum(gm) = sum_p [z_p > 0] g_p, sum(gm * xhat) =
+// sum_p [z_p > 0] g_p * (((z_p - shift) / scale - mean) * invstd).  Reads g and z (1/4 of the un-pooled map each) instead of
+// g, idx and y: 5.6 -> 2.1 GB at C3's finest level.  Channels whose |gamma| = |scale / invstd| is below 0.05 would amplify
+// the rounding of z by 1 / gamma: those fetch y at the argmax position (idx) like the un-pooled kernel.
+__global__ __launch_bounds__(256)
+void bn_pool_bwd_partial_pooled_kernel(const float* __restrict__ g, const float* __restrict__ z, const uint8_t* __restrict__ idx,
+                                       const float* __restrict__ y, const float* __restrict__ bn, float* __restrict__ partial,
+                                       int N, int H, int W, int OH, int OW, int C, int groups) {
+  extern __shared__ __attribute__((aligned(16))) double smd[];   // [2][RL][C]
+  const int C4 = C >> 2, RL = 256 / C4;
+  const int tid = threadIdx.x, col4 = tid % C4, rl = tid / C4;
+  const int c = col4 * 4;
+  const long long P = (long long)N * OH * OW;
+  const long long ppg = (P + groups - 1) / groups;
+  const long long pbeg = (long long)blockIdx.x * ppg;
+  const long long pend = pbeg + ppg < P ? pbeg + ppg : P;
+  const float4 sc4 = ld4(bn + c), sh4 = ld4(bn + C + c), mu4 = ld4(bn + 2 * C + c), is4 = ld4(bn + 3 * C + c);
+  const float sc[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, sh[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
+  const float mu[4] = {mu4.x, mu4.y, mu4.z, mu4.w}, is[4] = {is4.x, is4.y, is4.z, is4.w};
+  float rsc[4];
+  bool viaz[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { viaz[e] = fabsf(sc[e]) >= 0.05f * fabsf(is[e]); rsc[e] = viaz[e] ? 1.f / sc[e] : 0.f; }
+  double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+  for (long long q = pbeg + rl; q < pend; q += RL) {
+    const long long o = q * C + c;
+    const float4 gv4 = ld4(g + o), zv4 = ld4(z + o);
+    const float gv[4] = {gv4.x, gv4.y, gv4.z, gv4.w}, zv[4] = {zv4.x, zv4.y, zv4.z, zv4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (!(zv[e] > 0.f)) continue;
+      float yy;
+      if (viaz[e]) {
+        yy = (zv[e] - sh[e]) * rsc[e];
+      } else {                                           // (rare) the argmax position of this window
+        const int ox = (int)(q % OW);
+        const long long t = q / OW;
+        const int oy = (int)(t % OH), n = (int)(t / OH);
+        const int k = idx[o + e];
+        const int iy = 2 * oy - 1 + k / 3, ix = 2 * ox - 1 + k % 3;
+        yy = y[(((long long)n * H + iy) * W + ix) * C + c + e];
+      }
+      const float xh = (yy - mu[e]) * is[e];
+      a0[e] += (double)gv[e];
+      a1[e] = fma((double)gv[e], (double)xh, a1[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    smd[(0 * RL + rl) * C + c + e] = a0[e];
+    smd[(1 * RL + rl) * C + c + e] = a1[e];
+  }
+  __syncthreads();
+  for (int t = tid; t < 2 * C; t += 256) {
+    const int which = t / C, cc = t - which * C;
+    double s = 0.0;
+    for (int k = 0; k < RL; ++k) s += smd[(which * RL + k) * C + cc];
+    partial[((long long)blockIdx.x * 2 + which) * C + cc] = (float)s;
+  }
+}
+
 __global__ __launch_bounds__(256)
 void bn_pool_bwd_apply_kernel(const float* __restrict__ g, const uint8_t* __restrict__ idx, const float* __restrict__ y,
                               const float* __restrict__ bn, const float* __restrict__ gamma, const float* __restrict__ sums,
@@ -596,6 +659,18 @@ extern "C" int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const
   const size_t sh = (size_t)2 * (256 / (C / 4)) * C * sizeof(double);
   hipLaunchKernelGGL(bn_pool_bwd_partial_kernel, dim3((unsigned)groups), dim3(256), sh, dcs_stream(stream), g, idx, y, bn,
                      partial, N, H, W, OH, OW, C, groups, dcs_streams((long long)N * H * W * C * 4) ? 1 : 0);
+  DCS_LAUNCH_RET();
+}
+
+extern "C" int dcs_bn_pool_bwd_partial_pooled(const float* g, const float* z, const uint8_t* idx, const float* y,
+                                              const float* bn, float* partial, int N, int H, int W, int C, int groups,
+                                              void* stream) {
+  DCS_CHECK_ARG(g && z && idx && y && bn && partial && N > 0 && H > 0 && W > 0 && groups > 0);
+  DCS_CHECK_ARG(C >= 4 && C <= 1024 && (C & 3) == 0 && 256 % (C / 4) == 0 && dcs_aligned16(g) && dcs_aligned16(z));
+  const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  const size_t sh = (size_t)2 * (256 / (C / 4)) * C * sizeof(double);
+  hipLaunchKernelGGL(bn_pool_bwd_partial_pooled_kernel, dim3((unsigned)groups), dim3(256), sh, dcs_stream(stream), g, z, idx, y,
+                     bn, partial, N, H, W, OH, OW, C, groups);
   DCS_LAUNCH_RET();
 }
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "dcs_bn_relu_maxpool": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "dcs_maxpool_bwd": [_P, _P, _P, _I, _I, _I, _I, _P],
     "dcs_bn_pool_bwd_partial": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "dcs_bn_pool_bwd_partial_pooled": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "dcs_bn_pool_bwd_apply": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "dcs_upsample_add": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P],
     "dcs_upsample_add_stats": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P],

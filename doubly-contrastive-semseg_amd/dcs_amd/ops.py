@@ -977,6 +977,7 @@ def bn_relu_maxpool(y, bn):
     out = torch.empty((N, OH, OW, Cc), device=y.device, dtype=_F32)
     idx = torch.empty((N, OH, OW, Cc), device=y.device, dtype=torch.uint8)
     _call("dcs_bn_relu_maxpool", _p(_req(y)), _p(bn), _p(out), _p(idx), N, H, W, Cc, _stream())
+    idx._pooled = out                    # bn_pool_bwd takes its sums from the pooled tensors
     return out, idx
 
 
@@ -995,7 +996,12 @@ def bn_pool_bwd(g, idx, y, bn, gamma, dgamma=None, dbeta=None, acc_param=False, 
     N, H, W, Cc = y.shape
     grp = _groups((N * ((H + 1) // 2) * ((W + 1) // 2)) // 2)
     part = torch.empty((grp, 2, Cc), device=y.device, dtype=_F32)
-    _call("dcs_bn_pool_bwd_partial", _p(g), _p(idx), _p(y), _p(bn), _p(part), N, H, W, Cc, grp, _stream())
+    z = getattr(idx, "_pooled", None)
+    if z is not None and os.environ.get("DCS_POOL_SUMS", "1") != "0":
+        # the pooled output is beside the argmax indices: the two sums need only the pooled tensors (1/4 of the map)
+        _call("dcs_bn_pool_bwd_partial_pooled", _p(g), _p(z), _p(idx), _p(y), _p(bn), _p(part), N, H, W, Cc, grp, _stream())
+    else:
+        _call("dcs_bn_pool_bwd_partial", _p(g), _p(idx), _p(y), _p(bn), _p(part), N, H, W, Cc, grp, _stream())
     sums = torch.empty((2, Cc), device=y.device, dtype=_F32)
     _call("dcs_colsum_final", _p(part), _p(sums), 1, grp, Cc, 1.0, 0.0, _stream())
     dy = torch.empty_like(y)

@@ -273,6 +273,12 @@ int dcs_maxpool_bwd(const float* g, const uint8_t* idx, float* gz, int N, int H,
  * weight gradient scales dy by it). */
 int dcs_bn_pool_bwd_partial(const float* g, const uint8_t* idx, const float* y, const float* bn, float* partial,
                             int N, int H, int W, int C, int groups, void* stream);
+/* dcs_bn_pool_bwd_partial from the POOLED tensors: z [N,OH,OW,C] = the pooled output dcs_bn_relu_maxpool wrote.  A pooled
+ * gradient lands on its window's argmax, whose ReLU is open iff z > 0, and there y = (z - shift) / scale: the two sums
+ * need g and z only (1/4 of the un-pooled map each); channels with |gamma| < 0.05 read y at the argmax position (idx).
+ * Same partial layout; results equal dcs_bn_pool_bwd_partial's to fp32 rounding of xhat (not bitwise). */
+int dcs_bn_pool_bwd_partial_pooled(const float* g, const float* z, const uint8_t* idx, const float* y, const float* bn,
+                                   float* partial, int N, int H, int W, int C, int groups, void* stream);
 int dcs_bn_pool_bwd_apply(const float* g, const uint8_t* idx, const float* y, const float* bn, const float* gamma,
                           const float* sums, float* dy, float* dgamma, float* dbeta, int N, int H, int W, int C,
                           int acc_param, int training, uint32_t* dy_maxabs, void* stream);

@@ -341,7 +341,7 @@ def test_normalize_pyramid(ops, N, H, W):
 
 
 @pytest.mark.parametrize("N,H,W", [(2, 16, 24), (1, 17, 9), (1, 3, 3)])
-def test_bn_relu_maxpool_fwd_bwd(ops, N, H, W):
+def test_bn_relu_maxpool_fwd_bwd(ops, monkeypatch, N, H, W):
     C = 64
     y = rnd(N, H, W, C, seed=26)
     bn = torch.stack([rnd(C, seed=27), rnd(C, seed=28) * 0.3, torch.zeros(C), torch.ones(C)])
@@ -354,15 +354,20 @@ def test_bn_relu_maxpool_fwd_bwd(ops, N, H, W):
     bn[2], bn[3] = rnd(C, seed=30) * 0.1, 1.0 + 0.2 * rnd(C, seed=31).abs()
     gamma = 1.0 + 0.1 * rnd(C, seed=32)
     g2 = rnd(*oref.shape, seed=33)
-    for training, acc in ((True, False), (False, True)):
-        dg0, db0 = rnd(C, seed=34), rnd(C, seed=35)
-        dgd, dbd = dg0.to(DEV).clone(), db0.to(DEV).clone()
-        dy = ops.bn_pool_bwd(g2.to(DEV), idx, y.to(DEV), bn.to(DEV), gamma.to(DEV), dgamma=dgd, dbeta=dbd,
-                             acc_param=acc, training=training)
-        dgr, dbr = dg0.clone(), db0.clone()
-        ref = E.bn_pool_bwd(g2, iref, y, bn, gamma, dgamma=dgr, dbeta=dbr, acc_param=acc, training=training)
-        close(dy, ref, 2e-5, f"fused pool+bn bwd training={training}")
-        close(dgd, dgr, 2e-5, "fused pool+bn dgamma"); close(dbd, dbr, 2e-5, "fused pool+bn dbeta")
+    # sums: from the pooled tensors alone (dcs_bn_pool_bwd_partial_pooled; the random `scale` row has channels on either
+    # side of its |gamma| threshold, so both the z route and the argmax fetch run) and from the un-pooled map
+    assert idx._pooled is out
+    for pooled in ("1", "0"):
+        monkeypatch.setenv("DCS_POOL_SUMS", pooled)
+        for training, acc in ((True, False), (False, True)):
+            dg0, db0 = rnd(C, seed=34), rnd(C, seed=35)
+            dgd, dbd = dg0.to(DEV).clone(), db0.to(DEV).clone()
+            dy = ops.bn_pool_bwd(g2.to(DEV), idx, y.to(DEV), bn.to(DEV), gamma.to(DEV), dgamma=dgd, dbeta=dbd,
+                                 acc_param=acc, training=training)
+            dgr, dbr = dg0.clone(), db0.clone()
+            ref = E.bn_pool_bwd(g2, iref, y, bn, gamma, dgamma=dgr, dbeta=dbr, acc_param=acc, training=training)
+            close(dy, ref, 2e-5, f"fused pool+bn bwd training={training} pooled sums={pooled}")
+            close(dgd, dgr, 2e-5, "fused pool+bn dgamma"); close(dbd, dbr, 2e-5, "fused pool+bn dbeta")
 
 
 @pytest.mark.parametrize("IH,IW,OH,OW", [(4, 8, 8, 16), (3, 5, 6, 10), (2, 3, 3, 5), (1, 2, 2, 3), (5, 7, 9, 12), (6, 9, 24, 36),
