@@ -39,7 +39,9 @@ __device__ __forceinline__ float4 pro_apply(const float4 v, const float4 sc, con
 // output gradient this launch produces (same [M][dst_cstride] layout as dst), mask = the tensor whose sign is the ReLU
 // mask (nullable), bn = [scale, shift, mean, invstd] x C record, relu = derive the mask from y*scale+shift.
 // relu: 0 = ReLU mask from `mask > 0` (or none), 1 = from the recomputed BatchNorm output, 2 = `mask` points to BYTES, the four
-// mask bits of every float4 of the tensor (dcs_bn_act's mask8: 1 byte read instead of 16)
+// mask bits of every float4 of the tensor (dcs_bn_act's mask8: 1 byte read instead of 16); + 4: the destination receives the
+// MASKED value gm instead of the raw gradient (everything behind a residual block's output passes its ReLU, so nobody needs
+// the unmasked one -- and the BatchNorm backward that follows need not write gm again)
 struct BnBwdEpi { const float* y; const float* mask; const float* bn; int relu; };
 
 // Epilogue shared by the convolution kernels.  C/D layout of the 32x32 MFMA: col = lane&31,
@@ -132,7 +134,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
         if (do_bnb) {
           pre_y[p] = ld4s(bnb.y + ro + colv, nt);
           if (bnb.mask) {
-            if (bnb.relu == 2) pre_m[p].x = __uint_as_float((unsigned)reinterpret_cast<const unsigned char*>(bnb.mask)[(ro + colv) >> 2]);
+            if ((bnb.relu & 3) == 2) pre_m[p].x = __uint_as_float((unsigned)reinterpret_cast<const unsigned char*>(bnb.mask)[(ro + colv) >> 2]);
             else pre_m[p] = ld4s(bnb.mask + ro + colv, nt);
           }
         }
@@ -147,21 +149,23 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[TM][TN], float* smem
       float* q = dst + ro + colv;
       if (vec_ok && colv + 3 < Cout) {
         if (acc_dst) { const float4 o = PRE ? pre_o[PRE ? p : 0] : ld4s(q, nt); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-        st4s(q, v, nt);
+        const bool store_masked = do_bnb && (bnb.relu & 4) != 0;
+        if (!store_masked) st4s(q, v, nt);
         if (do_bnb) {
           const float4 yy = PRE ? pre_y[PRE ? p : 0] : ld4s(bnb.y + ro + colv, nt);
           float4 gm = v;
-          if (bnb.mask && bnb.relu == 2) {
+          if (bnb.mask && (bnb.relu & 3) == 2) {
             const unsigned m = PRE ? __float_as_uint(pre_m[PRE ? p : 0].x)
                                    : (unsigned)reinterpret_cast<const unsigned char*>(bnb.mask)[(ro + colv) >> 2];
             gm.x = (m & 1u) ? gm.x : 0.f; gm.y = (m & 2u) ? gm.y : 0.f; gm.z = (m & 4u) ? gm.z : 0.f; gm.w = (m & 8u) ? gm.w : 0.f;
           } else if (bnb.mask) {
             const float4 ms = PRE ? pre_m[PRE ? p : 0] : ld4s(bnb.mask + ro + colv, nt);
             gm.x = ms.x > 0.f ? gm.x : 0.f; gm.y = ms.y > 0.f ? gm.y : 0.f; gm.z = ms.z > 0.f ? gm.z : 0.f; gm.w = ms.w > 0.f ? gm.w : 0.f;
-          } else if (bnb.relu) {
+          } else if (bnb.relu & 3) {
             gm.x = fmaf(yy.x, b_sc.x, b_sh.x) > 0.f ? gm.x : 0.f; gm.y = fmaf(yy.y, b_sc.y, b_sh.y) > 0.f ? gm.y : 0.f;
             gm.z = fmaf(yy.z, b_sc.z, b_sh.z) > 0.f ? gm.z : 0.f; gm.w = fmaf(yy.w, b_sc.w, b_sh.w) > 0.f ? gm.w : 0.f;
           }
+          if (store_masked) st4s(q, gm, nt);
           b_s0.x += gm.x; b_s0.y += gm.y; b_s0.z += gm.z; b_s0.w += gm.w;
           b_s1.x = fmaf(gm.x, (yy.x - b_mu.x) * b_is.x, b_s1.x); b_s1.y = fmaf(gm.y, (yy.y - b_mu.y) * b_is.y, b_s1.y);
           b_s1.z = fmaf(gm.z, (yy.z - b_mu.z) * b_is.z, b_s1.z); b_s1.w = fmaf(gm.w, (yy.w - b_mu.w) * b_is.w, b_s1.w);

@@ -544,7 +544,14 @@ def _gather_launch(src, wgt, bias, dst, g, accumulate, stats, pro=None, bnb=None
     yb, mb, bnr, relu = bnb if bnb is not None else (None, None, None, False)
     m8 = getattr(mb, "_mask8", None) if (mb is not None and mask8_on()) else None
     if m8 is not None:                       # the byte mask dcs_bn_act left beside the tensor: relu = 2 (include/dcs_hip.h)
-        mb, relu = m8, 2
+        # + 4: the launch stores the MASKED gradient (nothing reads a residual block's incoming gradient except through its
+        # ReLU), so that bn_bwd(want_gm=True) can hand the tensor back as gm instead of writing it again
+        if os.environ.get("DCS_STORE_MASKED", "1") != "0":
+            dst._dcs_masked = mb
+            relu = 6
+        else:
+            relu = 2
+        mb = m8
     relu = int(relu)
     if (ns == 1 and g.stem and fwd and bias is None and pro is None and bnb is None and x3_ok(g) and stem7_ok(g) and
             _x2h_forward[0] and x2h_on()):
@@ -930,6 +937,8 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
     if want_dy:
         dy = dy_out if dy_out is not None else torch.empty_like(y)
     gm = torch.empty_like(y) if want_gm else None
+    if want_gm and masksrc is not None and getattr(g, "_dcs_masked", None) is masksrc:
+        gm = None                       # g arrived masked (conv_dgrad's epilogue, relu | 4): it IS gm
     smax = None
     if dy is not None and y.is_cuda and x2h_on():
         # the maximum of |dy| rides along (one integer atomicMax per wave): the convolutions that consume dy -- data and
@@ -941,6 +950,8 @@ def bn_bwd(g, y, bn, gamma, masksrc=None, relu=False, want_dy=True, want_gm=Fals
           1 if acc_param else 0, 1 if training else 0, _p(smax), _p(m8), _stream())
     if smax is not None:
         dy._dcs_max = smax
+    if want_gm and gm is None:
+        gm = g
     return dy, gm
 
 

@@ -78,7 +78,9 @@ int dcs_conv_gather(const float* src, const float* wgt, const float* bias, float
  * [ceil(M/DCS_CONV_BM)][2][Cout] receives per row tile sum(gm) and sum(gm * xhat), gm = (final dst value, after the
  * optional accumulate) * ReLU mask, xhat = (bn_y - mean) * invstd -- the sums dcs_colsum_partial(mode 1) would take in a
  * pass of its own.  bn_y (and bn_mask, nullable: mask = bn_mask > 0; else relu ? bn_y*scale+shift > 0 : 1) have dst's
- * layout; relu = 2: bn_mask points to the BYTE mask dcs_bn_act wrote for that tensor (four bits per float4; 1/16 of the bytes); dst must be dense (dst_cstride == Cout, Cout % 4 == 0).  Stride-2 data gradients are several launches (one
+ * layout; relu = 2: bn_mask points to the BYTE mask dcs_bn_act wrote for that tensor (four bits per float4; 1/16 of the bytes);
+ * relu | 4: dst receives the MASKED gradient gm instead of the raw one (a residual block's incoming gradient is only ever
+ * used behind its ReLU: the BatchNorm backward that follows then has no gm to write); dst must be dense (dst_cstride == Cout, Cout % 4 == 0).  Stride-2 data gradients are several launches (one
  * per input parity class), each with its own rows of part; dcs_colsum_final sums them all. */
 int dcs_conv_gather_bnbwd(const float* src, const float* wgt, float* dst, const DcsConvGeom* geom, int accumulate,
                           const float* bn_y, const float* bn_mask, const float* bn, int relu, float* part, void* stream);

@@ -158,6 +158,19 @@ def test_byte_relu_mask_beside_a_residual_output(ops, monkeypatch, N, H, W, Cc):
     g = rnd(N, H, W, Cc, seed=235).to(DEV)
     w = cl(rnd(Cc, Cc, 3, 3, seed=236, scale=0.05).to(DEV))
     dy = rnd(N, H, W, Cc, seed=237).to(DEV) * 1e-2
+    # relu | 4: the data gradient's epilogue stores the MASKED gradient and bn_bwd(want_gm=True) hands that tensor back as gm
+    wpk0 = ops.pack_dgrad_weight(w)
+    gxm, sm = ops.conv_dgrad(dy, wpk0, (H, W), 1, 1, bnb=(y, out, bn, False))
+    monkeypatch.setenv("DCS_STORE_MASKED", "0")
+    gxr, sr = ops.conv_dgrad(dy, wpk0, (H, W), 1, 1, bnb=(y, out, bn, False))
+    monkeypatch.delenv("DCS_STORE_MASKED")
+    assert (sm is None and sr is None) or torch.equal(sm, sr)
+    if sm is not None:
+        assert gxm._dcs_masked is out and not hasattr(gxr, "_dcs_masked")
+        assert torch.equal(gxm, gxr * (out > 0))
+        d_m, gm_m = ops.bn_bwd(gxm, y, bn, gam, masksrc=out, want_gm=True, sums=sm)
+        d_r, gm_r = ops.bn_bwd(gxr, y, bn, gam, masksrc=out, want_gm=True, sums=sr)
+        assert gm_m is gxm and gm_r is not gxr and torch.equal(gm_m, gm_r) and torch.equal(d_m, d_r)
     res = {}
     for on in ("1", "0"):
         monkeypatch.setenv("DCS_MASK8", on)
@@ -165,7 +178,7 @@ def test_byte_relu_mask_beside_a_residual_output(ops, monkeypatch, N, H, W, Cc):
         dg, db = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
         gx, sums = ops.conv_dgrad(dy, ops.pack_dgrad_weight(w), (H, W), 1, 1, bnb=(y, out, bn, False))
         dy2, _ = ops.bn_bwd(gx, y, bn, gam, masksrc=out, dgamma=dg, dbeta=db, sums=sums)
-        res[on] = (dyo, gx, sums, dy2, dg, db)
+        res[on] = (dyo, gx * (out > 0), sums, dy2, dg, db)      # (with the byte mask the launch stores gx already masked)
     for a, b in zip(res["1"], res["0"]):
         assert (a is None and b is None) or torch.equal(a, b)      # (a split-K launch of a tiny map carries no sums)
 
