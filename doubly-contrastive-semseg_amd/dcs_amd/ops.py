@@ -495,6 +495,7 @@ def x2h_on():
 # data (a freshly initialised ResNet-101 lets its activations grow through 33 residual blocks): it keeps the three-piece
 # bf16 kernels, whose range is fp32's.  Gradients are always scaled by their measured maximum.
 _x2h_forward = [True]
+_step_max_m = [0]                  # pixels of the largest convolution output since new_step (conv_wgrad's split policy)
 
 
 def new_step(training=True):
@@ -504,6 +505,7 @@ def new_step(training=True):
     _split_cache.clear()
     _max_pool["buf"] = None
     _x2h_forward[0] = bool(training)
+    _step_max_m[0] = 0
 
 
 def x3w_ok(g):
@@ -623,6 +625,7 @@ def conv_fwd(x, w, stride, pad, bias=None, dst_cs=None, want_stats=False, dil=1,
     N, H, W, Cin = x.shape
     Cout, Ktot, R, S = w.shape
     g = geom_fwd(N, H, W, Cin, Cout, R, S, stride, pad, None, dst_cs, dil, koff or 0, Ktot)
+    _step_max_m[0] = max(_step_max_m[0], N * g.DH * g.DW)
     cs = dst_cs or Cout
     ns = _ksplit(g, N * g.DH * g.DW, Cout) if bias is None else 1
     if out is not None:
@@ -751,7 +754,12 @@ def conv_wgrad(x, dy, dw, stride, pad, accumulate, dil=1, koff=None, pro=None):
         # splits, whose rounding biases cancel pairwise in the slab reduction
         if R == 3 and S == 3 and stride == 1 and pad == 1 and dil == 1 and W % 16 == 0:
             tiles = (-(-Cout // 64)) * (-(-Cin // 64))      # nine-tap kernel: one block per 64x64 tile and split
-            ns = max(2, min(-(-1024 // tiles), (M // 16) // 16))
+            # blocks per launch: 512 (one round of the chip's 2 x 256 block slots) in a step of large maps -- half the slab
+            # bytes to write and reduce, for every pyramid level (they share their launch) --, 1024 in a step of small ones
+            # (measured: C3 106.9 -> 105.4 ms with 512, C2 17.8-18.7 -> 19.4-19.7; C5 neutral).  "Large": the biggest
+            # convolution output of the forward had two million pixels or more.
+            nblk = int(os.environ.get("DCS_WGRAD_BLOCKS", "0")) or (512 if _step_max_m[0] >= (2 << 20) else 1024)
+            ns = max(2, min(-(-nblk // tiles), (M // 16) // 16))
         else:
             bt = 128 if (Cout > 64 and Cin > 64) else 64
             tiles = R * S * (-(-Cout // bt)) * (-(-Cin // bt))
@@ -804,6 +812,7 @@ def stem_conv(p, wp, want_stats=False):
     N, H, W, _ = p.shape
     g = geom_stem_fwd(N, H, W) if os.environ.get("DCS_STEM14", "1") != "0" else geom_stem(N, H, W)
     y = torch.empty((N, g.DH, g.DW, 64), device=p.device, dtype=_F32)
+    _step_max_m[0] = max(_step_max_m[0], N * g.DH * g.DW)
     if not want_stats:
         _gather_launch(p, wp, None, y, g, 0, None, fwd=True)
         return y
